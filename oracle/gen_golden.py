@@ -1,0 +1,248 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+TEST INFRASTRUCTURE.  Imports /root/reference (read-only) to produce small input/output
+vectors; the reference never travels to the GPU box, only these fixtures do.  Run:
+
+    python oracle/gen_golden.py
+
+What is captured:
+  predict_small.npz   weights (mu,rho) of M seeded BayesianNetworks, X, the eps the
+                      reference drew (torch.randn_like wrapped), all_predictions, mean, std,
+                      torch.quantile levels.
+  predict_cfg1.npz    config 1/2: data.py series + main.py:94-130 scaling -> X [365,11];
+                      M=5, S=100; eps is NOT stored (88 MB) - it is regenerated from
+                      ``eps_seed`` with torch's CPU generator in the reference's draw order
+                      (oracle.reference_rng_eps); stores mean, std, quantiles and a slice
+                      of all_predictions.
+  train_fwd.npz       train-mode forward (noise + live dropout masks, captured by a forward
+                      hook on model.dropout): eps, masks, outputs.
+  loss.npz            peak_weighted_loss value + autograd grad at N in {1, 13, 32, 4096}.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from models.bayesian_ensemble import BayesianNetwork, GPUBayesianEnsemble  # noqa: E402  (reference)
+from utils import peak_weighted_loss as ref_loss  # noqa: E402  (reference)
+from data import SyntheticDataGenerator  # noqa: E402  (reference)
+
+from oracle import bnn_oracle as orc  # noqa: E402
+
+Q_LEVELS = (0.025, 0.5, 0.975)
+
+
+class EpsRecorder:
+    """Wrap torch.randn_like so every draw of the reference is recorded in order."""
+
+    def __enter__(self):
+        self.draws = []
+        self._orig = torch.randn_like
+
+        def wrapped(t, *a, **k):
+            out = self._orig(t, *a, **k)
+            self.draws.append(out.detach().clone().reshape(-1))
+            return out
+
+        torch.randn_like = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._orig
+
+
+def make_members(input_dim: int, M: int, seed: int, perturb: bool = True):
+    torch.manual_seed(seed)
+    members = []
+    for _ in range(M):
+        net = BayesianNetwork(input_dim)
+        if perturb:  # untrained nets have bias_mu == 0 and rho == -3 everywhere: make them generic
+            with torch.no_grad():
+                for l in list(net.hidden_layers) + [net.output_layer]:
+                    l.bias_mu.add_(0.1 * torch.randn_like(l.bias_mu))
+                    l.weight_rho.add_(0.5 * torch.randn_like(l.weight_rho))
+                    l.bias_rho.add_(0.5 * torch.randn_like(l.bias_rho))
+        members.append(net)
+    return members
+
+
+def run_reference_predict(members, X, S, eps_seed):
+    ens = GPUBayesianEnsemble(input_dim=X.shape[1], n_models=len(members), device=torch.device("cpu"))
+    ens.models = members
+    captured = {}
+    orig_reshape = torch.Tensor.reshape
+
+    torch.manual_seed(eps_seed)
+    with EpsRecorder() as rec:
+        # capture all_predictions (bayesian_ensemble.py:242) through a mean() hook-free route:
+        # re-run the same loops is not needed - std/mean are returned; all_predictions is
+        # rebuilt below from the recorded eps through the reference modules' own forward.
+        mean, std = ens.predict(X, num_samples=S)
+    P = orc.n_params(X.shape[1])
+    eps = torch.cat(rec.draws).reshape(len(members), S, P)
+    return mean.rename(None), std.rename(None), eps
+
+
+def reference_all_predictions(members, X, eps):
+    """Replay the recorded eps through the reference modules (randn_like patched to feed them)."""
+    M, S, P = eps.shape
+    offs = orc.param_offsets(X.shape[1])
+    out = torch.empty(M * S, X.shape[0])
+    orig = torch.randn_like
+    try:
+        for m, net in enumerate(members):
+            net.eval()
+            for s in range(S):
+                queue = []
+                for (wo, bo, k_in, k_out) in offs:
+                    queue.append(eps[m, s, wo:wo + k_in * k_out].view(k_out, k_in))
+                    queue.append(eps[m, s, bo:bo + k_out])
+                it = iter(queue)
+                torch.randn_like = lambda t, *a, **k: next(it).clone()
+                with torch.no_grad():
+                    out[m * S + s] = net(X, sample=True).rename(None)
+    finally:
+        torch.randn_like = orig
+    return out
+
+
+def gen_predict_small():
+    F_in, B, M, S = 11, 37, 3, 6
+    members = make_members(F_in, M, seed=101)
+    torch.manual_seed(7)
+    X = torch.randn(B, F_in)
+    mean, std, eps = run_reference_predict(members, X, S, eps_seed=202)
+    allp = reference_all_predictions(members, X, eps)
+    assert torch.equal(allp.mean(0), mean) and torch.equal(allp.std(0), std)
+    mu, rho = orc.pack_members(members)
+    q = torch.quantile(allp, torch.tensor(Q_LEVELS), dim=0)
+    np.savez_compressed(os.path.join(OUT, "predict_small.npz"), X=X.numpy(), mu=mu.numpy(), rho=rho.numpy(),
+                        eps=eps.numpy(), all_predictions=allp.numpy(), mean=mean.numpy(), std=std.numpy(),
+                        q_levels=np.array(Q_LEVELS), quantiles=q.numpy())
+    # other input widths the 32 feature subsets produce (main.py:38-57 -> F = 7..11)
+    for F_alt in (7, 9):
+        members = make_members(F_alt, 2, seed=300 + F_alt)
+        torch.manual_seed(8)
+        Xa = torch.randn(19, F_alt)
+        mean, std, eps = run_reference_predict(members, Xa, 4, eps_seed=400 + F_alt)
+        allp = reference_all_predictions(members, Xa, eps)
+        mu, rho = orc.pack_members(members)
+        np.savez_compressed(os.path.join(OUT, f"predict_small_F{F_alt}.npz"), X=Xa.numpy(), mu=mu.numpy(),
+                            rho=rho.numpy(), eps=eps.numpy(), all_predictions=allp.numpy(), mean=mean.numpy(),
+                            std=std.numpy())
+
+
+def make_cfg1_inputs(seed: int):
+    """data.py defaults + main.py:94-130 (concat, two StandardScalers) -> X_scaled, y_scaled."""
+    from sklearn.preprocessing import StandardScaler
+    torch.manual_seed(seed)
+    data = SyntheticDataGenerator().generate_data()
+    X = torch.cat([data.features.rename(None), data.temporal.rename(None)], dim=1)
+    y = data.target.rename(None)
+    sx, sy = StandardScaler(), StandardScaler()
+    Xs = torch.tensor(sx.fit_transform(X.numpy()))
+    ys = torch.tensor(sy.fit_transform(y.numpy().reshape(-1, 1))).squeeze(-1)
+    return X, y, Xs, ys, float(sy.scale_[0]), float(sy.mean_[0])
+
+
+def gen_predict_cfg1():
+    M, S = 5, 100
+    X_raw, y_raw, Xs, ys, y_scale, y_mean = make_cfg1_inputs(seed=2025)
+    assert Xs.dtype == torch.float32 and Xs.shape == (365, 11)
+    members = make_members(11, M, seed=11)
+    eps_seed = 12345
+    mean, std, eps = run_reference_predict(members, Xs, S, eps_seed=eps_seed)
+    # the reference's draws == torch CPU generator stream in draw order (no storage needed)
+    assert torch.equal(eps, orc.reference_rng_eps(eps_seed, M, S, 11))
+    allp = reference_all_predictions(members, Xs, eps)
+    assert torch.equal(allp.mean(0), mean) and torch.equal(allp.std(0), std)
+    mu, rho = orc.pack_members(members)
+    q = torch.quantile(allp, torch.tensor(Q_LEVELS), dim=0)
+    # main.py:174-177 de-scaling
+    descaled_mean = mean.numpy().astype(np.float64) * y_scale + y_mean
+    descaled_std = std.numpy() * y_scale
+    np.savez_compressed(os.path.join(OUT, "predict_cfg1.npz"), X_raw=X_raw.numpy(), y_raw=y_raw.numpy(),
+                        X=Xs.numpy(), y=ys.numpy(), y_scale=y_scale, y_mean=y_mean, mu=mu.numpy(), rho=rho.numpy(),
+                        eps_seed=eps_seed, M=M, S=S, mean=mean.numpy(), std=std.numpy(),
+                        q_levels=np.array(Q_LEVELS), quantiles=q.numpy(),
+                        all_predictions_head=allp[:8].numpy(), all_predictions_tail=allp[-4:].numpy(),
+                        descaled_mean=descaled_mean, descaled_std=descaled_std)
+
+
+def gen_train_fwd():
+    F_in, B, npass = 11, 13, 3   # 13 = the reference's last mini-batch (365 % 32)
+    members = make_members(F_in, 1, seed=55)
+    net = members[0]
+    net.train()
+    masks = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        # mask = (out != 0) is ambiguous where x == 0; recover from out/x where x != 0
+        keep = torch.where(x != 0, (out != 0), torch.ones_like(out, dtype=torch.bool))
+        masks.append(keep.to(torch.uint8).clone())
+
+    h = net.dropout.register_forward_hook(hook)
+    torch.manual_seed(9)
+    X = torch.randn(B, F_in)
+    outs = []
+    torch.manual_seed(77)
+    with EpsRecorder() as rec:
+        for _ in range(npass):
+            with torch.no_grad():
+                outs.append(net(X, sample=True).rename(None).clone())
+    h.remove()
+    P = orc.n_params(F_in)
+    eps = torch.cat(rec.draws).reshape(npass, P)
+    mu, rho = orc.pack_members(members)
+    np.savez_compressed(os.path.join(OUT, "train_fwd.npz"), X=X.numpy(), mu=mu.numpy(), rho=rho.numpy(),
+                        eps=eps.numpy(), out=torch.stack(outs).numpy(),
+                        mask0=torch.stack(masks[0::3]).numpy(), mask1=torch.stack(masks[1::3]).numpy(),
+                        mask2=torch.stack(masks[2::3]).numpy())
+
+
+def gen_loss():
+    rec = {}
+    for N in (1, 2, 13, 32, 4096):
+        torch.manual_seed(1000 + N)
+        t = torch.randn(N)
+        t = t + (torch.rand(N) > 0.9).float() * 2.0  # a few peaks
+        p = (t + 0.3 * torch.randn(N)).requires_grad_(True)
+        L = ref_loss(p, t)
+        L.backward()
+        p64 = p.detach().double().requires_grad_(True)
+        L64 = ref_loss(p64, t.double())
+        L64.backward()
+        rec[f"p_{N}"] = p.detach().numpy()
+        rec[f"t_{N}"] = t.numpy()
+        rec[f"loss_{N}"] = L.detach().numpy()
+        rec[f"grad_{N}"] = p.grad.numpy()
+        rec[f"loss64_{N}"] = L64.detach().numpy()
+        rec[f"grad64_{N}"] = p64.grad.numpy()
+    # non-default alpha/beta
+    torch.manual_seed(5)
+    t = torch.randn(257)
+    p = (t + 0.5 * torch.randn(257)).requires_grad_(True)
+    L = ref_loss(p, t, alpha=3.5, beta=1.0)
+    L.backward()
+    rec.update(p_ab=p.detach().numpy(), t_ab=t.numpy(), loss_ab=L.detach().numpy(), grad_ab=p.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **rec)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_predict_small()
+    gen_predict_cfg1()
+    gen_train_fwd()
+    gen_loss()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
