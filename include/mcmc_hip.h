@@ -1,0 +1,146 @@
+/* libmcmc_hip.so - C ABI of the MI355X (gfx950) Monte Carlo predictive path.
+ *
+ * The reference (fintkz/mcmc) has no FFI layer: the path sits behind the Python class
+ * GPUBayesianEnsemble (models/bayesian_ensemble.py:95-256) and utils.peak_weighted_loss
+ * (utils.py:7-28).  These entry points are what a binding for that path calls (ctypes in
+ * mcmc_amd/_lib.py; INTEGRATION.md shows the stub).  Each one cites the reference lines it
+ * replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MCMC_E* code on error; the message is
+ *     available from mcmc_last_error() (thread-local);
+ *   - all buffers are DEVICE pointers owned by the caller (torch tensors' data_ptr()) unless a
+ *     parameter says "host"; nothing is allocated or freed behind the caller's back;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls only enqueue;
+ *   - a context is bound to one device, is not thread-safe, and must be used with that device
+ *     current - one context per device per thread, like the reference's single-threaded use
+ *     (main.py:248-251).
+ *
+ * Vocabulary: member = one BayesianNetwork of the ensemble; sample = one Monte Carlo weight
+ * draw; pair = (member, sample); unit = pair x timestep-row.  Pairs are processed in the order
+ * q = 0 .. M*S-1 with member = q % M, sample = q / M (every chunk of consecutive q holds all
+ * members evenly); the GLOBAL pair id g = member*S + sample is the reference's row index in
+ * all_predictions (bayesian_ensemble.py:242), indexes injected eps and keys Philox.
+ */
+#ifndef MCMC_HIP_H
+#define MCMC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMC_OK 0
+#define MCMC_EINVAL (-1)  /* bad argument (shape, dtype, null pointer, alignment) */
+#define MCMC_EHIP (-2)    /* a HIP runtime call or kernel launch failed           */
+#define MCMC_ESTATE (-3)  /* context used on the wrong device / destroyed         */
+
+#define MCMC_DT_F32 0  /* fp32 operands, fp32 MFMA accumulate (exact fp32 FMA chain)      */
+#define MCMC_DT_BF16 1 /* bf16 operands, fp32 MFMA accumulate                             */
+
+#define MCMC_NOISE_NONE 0     /* W = mu            (sample=False, bayesian_ensemble.py:45-47) */
+#define MCMC_NOISE_INJECTED 1 /* W = mu + eps*exp(rho), eps supplied by the caller          */
+#define MCMC_NOISE_PHILOX 2   /* eps from Philox4x32-10 keyed (seed; g, param index)        */
+
+typedef struct mcmc_ctx mcmc_ctx;
+typedef void* mcmc_stream_t;
+
+/* Thread-local text of the last error (never NULL). */
+const char* mcmc_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int mcmc_abi_version(void);
+
+/* One context per device.  Replaces nothing in the reference (it keeps its state in torch);
+ * holds the device id and cached device properties. */
+int mcmc_ctx_create(int device, mcmc_ctx** out);
+int mcmc_ctx_destroy(mcmc_ctx* ctx);
+
+/* ---- layout queries (host only, no device work) ---------------------------------------- */
+/* Parameters of one member in the flat layout = noise draws per pair:
+ * 44,289 at input_dim 11 (bayesian_ensemble.py:17-22,61-70). */
+int64_t mcmc_param_count(int input_dim);
+/* Bytes of one packed input matrix / of one pair's packed effective weights. */
+int64_t mcmc_xpack_bytes(int64_t n_rows, int input_dim, int dtype);
+int64_t mcmc_wpack_bytes(int input_dim, int dtype);
+
+/* ---- piece 1: member x sample forward ---------------------------------------------------- */
+/* X [n_rows, input_dim] fp32 row-major -> kernel input layout (padded, bias column, dtype).
+ * Replaces X.to(device) / x.rename(None) staging (bayesian_ensemble.py:219, :76). */
+int mcmc_pack_x(mcmc_ctx* ctx, const float* X, int64_t n_rows, int input_dim, int dtype,
+                void* xpack, mcmc_stream_t stream);
+
+/* Effective weights of pairs q = pair_begin .. pair_begin+pair_count-1:
+ *   W = mu + eps * exp(rho)   (bayesian_ensemble.py:43-44; exp, not softplus)
+ * written as MFMA operand fragments, wpack[pair_count][mcmc_wpack_bytes].
+ *   mu, rho : [n_members, P] fp32 flat layout (W then b per layer, layers in order)
+ *   eps     : MCMC_NOISE_INJECTED: [n_members*n_samples, P] fp32 indexed by global pair id g
+ *             (same flat order = the reference's draw order); otherwise ignored (may be NULL)
+ *   seed    : MCMC_NOISE_PHILOX key. */
+int mcmc_sample_weights(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members,
+                        int n_samples, int input_dim, int64_t pair_begin, int pair_count,
+                        int noise_mode, const float* eps, uint64_t seed, int dtype, void* wpack,
+                        mcmc_stream_t stream);
+
+/* Raw Philox noise eps[pair_count, P] fp32 for global pair ids g = g_begin.. (test/inspection:
+ * what MCMC_NOISE_PHILOX feeds into mcmc_sample_weights). */
+int mcmc_philox_eps(mcmc_ctx* ctx, uint64_t seed, int64_t g_begin, int pair_count, int input_dim,
+                    float* eps, mcmc_stream_t stream);
+
+/* The fused MLP forward of BayesianNetwork (bayesian_ensemble.py:73-92) for pair_count pairs:
+ *   h = X; 3 x { h = elu(h W^T + b); h = h * mask * keep_scale }; y = h w3^T + b3
+ * Y[c*ldY + row] = y of pair c, row (fp32).  ldY >= n_rows, multiple of 4.
+ *   mask0/1/2 : optional uint8 keep-masks [pair_count, n_rows, 256/128/64] (train-mode dropout,
+ *               bayesian_ensemble.py:86); NULL = identity (eval mode, what predict() runs,
+ *               bayesian_ensemble.py:215-216).  keep_scale = fp32(1/(1-p)).
+ *               Masks are supported for MCMC_DT_F32 only. */
+int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim,
+                 const void* wpack, int pair_count, const uint8_t* mask0, const uint8_t* mask1,
+                 const uint8_t* mask2, float keep_scale, float* Y, int64_t ldY,
+                 mcmc_stream_t stream);
+
+/* ---- piece 2: streaming per-timestep statistics ------------------------------------------- */
+/* Replaces torch.stack + reshape + mean(0) + std(0) (bayesian_ensemble.py:234-246) without
+ * keeping all M*S samples: the caller feeds chunks Y[n_pairs, ldY] and the per-row state
+ *   sum, sumsq : [n_rows] fp64      hist : [n_rows, nbins] uint16 (optional, NULL = no quantiles)
+ *   lo, inv_w  : [n_rows] fp32 histogram placement (mcmc_reduce_set_edges)
+ * is updated in place.  State must be zeroed by the caller before the first chunk.
+ * nbins: 64, 128, 256 or 512; at most 65,535 samples per row in total (uint16 counts). */
+int mcmc_reduce_update(mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows,
+                       double* sum, double* sumsq, const float* lo, const float* inv_w,
+                       uint16_t* hist, int nbins, mcmc_stream_t stream);
+
+/* Histogram placement from pilot moments (n0 samples per row already in sum/sumsq): interior
+ * bins 1..nbins-2 tile [mean - k*std, mean + k*std), bins 0 and nbins-1 catch the tails. */
+int mcmc_reduce_set_edges(mcmc_ctx* ctx, int64_t n_rows, int64_t n0, const double* sum,
+                          const double* sumsq, int nbins, float range_sigmas, float* lo,
+                          float* inv_w, mcmc_stream_t stream);
+
+/* mean = sum/n, std = unbiased (n-1) like torch.std (bayesian_ensemble.py:245-246; NaN at n=1),
+ * quant[k, row] = histogram quantile at q_levels[k] (host fp64 array, n_q <= 8; position q*(n-1)
+ * like torch.quantile 'linear', interpolated inside the bin).  hist may be NULL iff n_q == 0. */
+int mcmc_reduce_finalize(mcmc_ctx* ctx, int64_t n_rows, int64_t n, const double* sum,
+                         const double* sumsq, const uint16_t* hist, const float* lo,
+                         const float* inv_w, int nbins, const double* q_levels, int n_q,
+                         float* mean, float* std, float* quant, mcmc_stream_t stream);
+
+/* ---- piece 3: fused peak-weighted loss (utils.py:7-28) ------------------------------------ */
+/* Three streaming passes over this rank's slice p,t [n]; the partial sums live in device
+ * memory so a data-parallel caller can all-reduce them between passes (n_total = global N).
+ *   pass 1: stats[0..2] += { sum t, sum t^2, sum |p-t| }                     (utils.py:17-18,22-23)
+ *   pass 2: part[0..1]  += { sum d^2 w, G = sum k d^2 g' }                   (utils.py:19-28)
+ *   pass 3: grad[j] = grad_scale/N * [2 d w + (alpha-1) sign(d) (k d^2 g' - G/N)]
+ * loss = part[0]/n_total.  stats/part are fp64[4] each, zeroed by the caller. */
+int mcmc_loss_stats(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, double* stats,
+                    mcmc_stream_t stream);
+int mcmc_loss_forward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total,
+                      const double* stats, float alpha, float beta, double* part,
+                      mcmc_stream_t stream);
+int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total,
+                       const double* stats, const double* part, float alpha, float beta,
+                       float grad_scale, float* grad, mcmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMC_HIP_H */

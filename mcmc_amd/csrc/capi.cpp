@@ -1,0 +1,222 @@
+// extern "C" entry points of libmcmc_hip.so: argument validation + dispatch to the launchers.
+// Declarations and the reference lines each one replaces: include/mcmc_hip.h.
+#include <string.h>
+
+#include <new>
+
+#include "common.hpp"
+
+namespace mcmc {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static int check_dims(int input_dim, int dtype) {
+    MCMC_REQUIRE(input_dim >= 1 && input_dim <= kMaxInputDim, "input_dim must be in [1, %d] (got %d)", kMaxInputDim, input_dim);
+    MCMC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dtype must be MCMC_DT_F32 or MCMC_DT_BF16 (got %d)", dtype);
+    return MCMC_OK;
+}
+
+}  // namespace mcmc
+
+using namespace mcmc;
+
+extern "C" {
+
+const char* mcmc_last_error(void) { return g_err; }
+
+int mcmc_abi_version(void) { return 1; }
+
+int mcmc_ctx_create(int device, mcmc_ctx** out) {
+    MCMC_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    MCMC_REQUIRE(device >= 0 && device < count, "device %d out of range (%d visible)", device, count);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(MCMC_EHIP, "device %d is %s; this library holds gfx950 (MI355X) code only", device, prop.gcnArchName);
+    mcmc_ctx* c = new (std::nothrow) mcmc_ctx;
+    if (!c) return set_error(MCMC_EHIP, "out of host memory");
+    c->magic = kCtxMagic;
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    c->lds_per_block = prop.sharedMemPerBlock;
+    *out = c;
+    return MCMC_OK;
+}
+
+int mcmc_ctx_destroy(mcmc_ctx* ctx) {
+    if (!ctx || ctx->magic != kCtxMagic) return set_error(MCMC_ESTATE, "invalid or destroyed context");
+    ctx->magic = 0;
+    delete ctx;
+    return MCMC_OK;
+}
+
+int64_t mcmc_param_count(int input_dim) {
+    if (input_dim < 1 || input_dim > kMaxInputDim) return set_error(MCMC_EINVAL, "input_dim must be in [1, %d]", kMaxInputDim);
+    return flat_param_count(input_dim);
+}
+
+int64_t mcmc_xpack_bytes(int64_t n_rows, int input_dim, int dtype) {
+    if (int rc = check_dims(input_dim, dtype)) return rc;
+    if (n_rows < 0) return set_error(MCMC_EINVAL, "n_rows < 0");
+    return rows_pad(n_rows) * k0_pad(input_dim, dtype) * (dtype == DT_F32 ? 4 : 2);
+}
+
+int64_t mcmc_wpack_bytes(int input_dim, int dtype) {
+    if (int rc = check_dims(input_dim, dtype)) return rc;
+    return dtype == DT_F32 ? WPackF32(input_dim).total * 4 : WPackBF16(input_dim).total;
+}
+
+int mcmc_pack_x(mcmc_ctx* ctx, const float* X, int64_t n_rows, int input_dim, int dtype, void* xpack, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_dims(input_dim, dtype)) return rc;
+    MCMC_REQUIRE(n_rows >= 0, "n_rows < 0");
+    if (n_rows == 0) return MCMC_OK;
+    MCMC_REQUIRE(X && xpack, "X / xpack is NULL");
+    MCMC_REQUIRE(aligned16(xpack), "xpack must be 16-byte aligned");
+    return launch_pack_x(X, n_rows, input_dim, dtype, xpack, (hipStream_t)stream);
+}
+
+int mcmc_sample_weights(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members, int n_samples, int input_dim,
+                        int64_t pair_begin, int pair_count, int noise_mode, const float* eps, uint64_t seed, int dtype,
+                        void* wpack, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_dims(input_dim, dtype)) return rc;
+    MCMC_REQUIRE(n_members >= 1 && n_samples >= 1, "n_members and n_samples must be >= 1");
+    MCMC_REQUIRE((int64_t)n_members * n_samples <= 0x7FFFFFFFLL, "n_members * n_samples exceeds 2^31-1");
+    MCMC_REQUIRE(pair_count >= 0 && pair_begin >= 0 && pair_begin + pair_count <= (int64_t)n_members * n_samples,
+                 "pair range [%lld, +%d) outside 0..%lld", (long long)pair_begin, pair_count, (long long)n_members * n_samples);
+    MCMC_REQUIRE(noise_mode >= MCMC_NOISE_NONE && noise_mode <= MCMC_NOISE_PHILOX, "bad noise_mode %d", noise_mode);
+    if (pair_count == 0) return MCMC_OK;
+    MCMC_REQUIRE(mu && rho && wpack, "mu / rho / wpack is NULL");
+    MCMC_REQUIRE(noise_mode != MCMC_NOISE_INJECTED || eps, "MCMC_NOISE_INJECTED needs eps");
+    MCMC_REQUIRE(aligned16(wpack), "wpack must be 16-byte aligned");
+    return launch_sample_weights(mu, rho, n_members, n_samples, input_dim, pair_begin, pair_count, noise_mode, eps, seed, dtype,
+                                 wpack, (hipStream_t)stream);
+}
+
+int mcmc_philox_eps(mcmc_ctx* ctx, uint64_t seed, int64_t g_begin, int pair_count, int input_dim, float* eps, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_dims(input_dim, DT_F32)) return rc;
+    MCMC_REQUIRE(pair_count >= 0 && g_begin >= 0 && g_begin + pair_count <= 0x7FFFFFFFLL, "bad pair range");
+    if (pair_count == 0) return MCMC_OK;
+    MCMC_REQUIRE(eps, "eps is NULL");
+    return launch_philox_eps(seed, g_begin, pair_count, input_dim, eps, (hipStream_t)stream);
+}
+
+int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int pair_count,
+                 const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, float keep_scale, float* Y, int64_t ldY,
+                 mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_dims(input_dim, dtype)) return rc;
+    MCMC_REQUIRE(n_rows >= 0 && pair_count >= 0, "n_rows / pair_count < 0");
+    if (n_rows == 0 || pair_count == 0) return MCMC_OK;
+    MCMC_REQUIRE(xpack && wpack && Y, "xpack / wpack / Y is NULL");
+    MCMC_REQUIRE(aligned16(xpack) && aligned16(wpack), "xpack and wpack must be 16-byte aligned");
+    MCMC_REQUIRE(ldY >= n_rows && ldY % 4 == 0, "ldY must be >= n_rows and a multiple of 4 (got %lld)", (long long)ldY);
+    const bool any = mask0 || mask1 || mask2, all = mask0 && mask1 && mask2;
+    MCMC_REQUIRE(any == all, "dropout masks: pass all three or none");
+    if (dtype == DT_F32)
+        return launch_forward_f32((const float*)xpack, n_rows, input_dim, (const float*)wpack, pair_count, mask0, mask1, mask2,
+                                  keep_scale, Y, ldY, (hipStream_t)stream);
+    MCMC_REQUIRE(!any, "dropout masks are supported for MCMC_DT_F32 only");
+    return launch_forward_bf16(ctx, xpack, n_rows, input_dim, wpack, pair_count, Y, ldY, (hipStream_t)stream);
+}
+
+static int check_nbins(int nbins) {
+    MCMC_REQUIRE(nbins == 64 || nbins == 128 || nbins == 256 || nbins == 512, "nbins must be 64, 128, 256 or 512 (got %d)", nbins);
+    return MCMC_OK;
+}
+
+int mcmc_reduce_update(mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum, double* sumsq,
+                       const float* lo, const float* inv_w, uint16_t* hist, int nbins, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n_rows >= 0 && n_pairs >= 0, "n_rows / n_pairs < 0");
+    if (n_rows == 0 || n_pairs == 0) return MCMC_OK;
+    MCMC_REQUIRE(Y && sum && sumsq, "Y / sum / sumsq is NULL");
+    MCMC_REQUIRE(ldY >= n_rows, "ldY < n_rows");
+    if (hist) {
+        if (int rc = check_nbins(nbins)) return rc;
+        MCMC_REQUIRE(lo && inv_w, "hist needs lo and inv_w (mcmc_reduce_set_edges)");
+        MCMC_REQUIRE((reinterpret_cast<uintptr_t>(hist) & 3u) == 0, "hist must be 4-byte aligned");
+    }
+    return launch_reduce_update(ctx, Y, ldY, n_pairs, n_rows, sum, sumsq, lo, inv_w, hist, nbins, (hipStream_t)stream);
+}
+
+int mcmc_reduce_set_edges(mcmc_ctx* ctx, int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins,
+                          float range_sigmas, float* lo, float* inv_w, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_nbins(nbins)) return rc;
+    MCMC_REQUIRE(n_rows >= 0 && n0 >= 1, "n_rows < 0 or n0 < 1");
+    MCMC_REQUIRE(range_sigmas > 0.0f, "range_sigmas must be > 0");
+    if (n_rows == 0) return MCMC_OK;
+    MCMC_REQUIRE(sum && sumsq && lo && inv_w, "NULL pointer");
+    return launch_set_edges(n_rows, n0, sum, sumsq, nbins, range_sigmas, lo, inv_w, (hipStream_t)stream);
+}
+
+int mcmc_reduce_finalize(mcmc_ctx* ctx, int64_t n_rows, int64_t n, const double* sum, const double* sumsq, const uint16_t* hist,
+                         const float* lo, const float* inv_w, int nbins, const double* q_levels, int n_q, float* mean, float* std,
+                         float* quant, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n_rows >= 0 && n >= 1, "n_rows < 0 or n < 1");
+    MCMC_REQUIRE(n_q >= 0 && n_q <= 8, "n_q must be in [0, 8]");
+    if (n_rows == 0) return MCMC_OK;
+    MCMC_REQUIRE(sum && sumsq && mean && std, "NULL pointer");
+    if (n_q > 0) {
+        if (int rc = check_nbins(nbins)) return rc;
+        MCMC_REQUIRE(hist && lo && inv_w && q_levels && quant, "quantiles need hist, lo, inv_w, q_levels, quant");
+        MCMC_REQUIRE(n <= 65535, "uint16 histogram holds at most 65,535 samples per row (n = %lld)", (long long)n);
+        for (int i = 0; i < n_q; ++i) MCMC_REQUIRE(q_levels[i] >= 0.0 && q_levels[i] <= 1.0, "q_levels[%d] outside [0,1]", i);
+    }
+    return launch_finalize(n_rows, n, sum, sumsq, hist, lo, inv_w, nbins, q_levels, n_q, mean, std, quant, (hipStream_t)stream);
+}
+
+static int check_loss(const float* p, const float* t, int64_t n, int64_t n_total) {
+    MCMC_REQUIRE(n >= 0 && n_total >= n && n_total >= 1, "need 0 <= n <= n_total and n_total >= 1");
+    MCMC_REQUIRE(n == 0 || (p && t), "p / t is NULL");
+    MCMC_REQUIRE(aligned16(p) && aligned16(t), "p and t must be 16-byte aligned");
+    return MCMC_OK;
+}
+
+int mcmc_loss_stats(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, double* stats, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_loss(p, t, n, n > 0 ? n : 1)) return rc;
+    MCMC_REQUIRE(stats, "stats is NULL");
+    if (n == 0) return MCMC_OK;
+    return launch_loss_stats(ctx, p, t, n, stats, (hipStream_t)stream);
+}
+
+int mcmc_loss_forward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total, const double* stats, float alpha,
+                      float beta, double* part, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_loss(p, t, n, n_total)) return rc;
+    MCMC_REQUIRE(stats && part, "stats / part is NULL");
+    if (n == 0) return MCMC_OK;
+    return launch_loss_forward(ctx, p, t, n, n_total, stats, alpha, beta, part, (hipStream_t)stream);
+}
+
+int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total, const double* stats,
+                       const double* part, float alpha, float beta, float grad_scale, float* grad, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_loss(p, t, n, n_total)) return rc;
+    MCMC_REQUIRE(stats && part, "stats / part is NULL");
+    if (n == 0) return MCMC_OK;
+    MCMC_REQUIRE(grad && aligned16(grad), "grad is NULL or not 16-byte aligned");
+    return launch_loss_backward(ctx, p, t, n, n_total, stats, part, alpha, beta, grad_scale, grad, (hipStream_t)stream);
+}
+
+}  // extern "C"

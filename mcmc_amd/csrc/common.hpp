@@ -1,0 +1,69 @@
+// Shared host-side plumbing of libmcmc_hip.so: error text, context, launch checks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mcmc_hip.h"
+#include "layout.hpp"
+
+struct mcmc_ctx {
+    uint32_t magic;
+    int device;
+    int num_cu;
+    size_t lds_per_block;
+};
+
+namespace mcmc {
+
+constexpr uint32_t kCtxMagic = 0x6D636D63u;
+
+int set_error(int code, const char* fmt, ...);
+
+inline int check_ctx(const mcmc_ctx* ctx) {
+    if (!ctx || ctx->magic != kCtxMagic) return set_error(MCMC_ESTATE, "invalid or destroyed context");
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev != ctx->device)
+        return set_error(MCMC_ESTATE, "context belongs to device %d but device %d is current", ctx->device, dev);
+    return MCMC_OK;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return MCMC_OK;
+}
+
+#define MCMC_REQUIRE(cond, ...)                                       \
+    do {                                                              \
+        if (!(cond)) return mcmc::set_error(MCMC_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// kernel launchers (one per .hip file)
+int launch_pack_x(const float* X, int64_t n_rows, int F, int dtype, void* xpack, hipStream_t s);
+int launch_sample_weights(const float* mu, const float* rho, int M, int S, int F, int64_t pair_begin, int pair_count,
+                          int noise_mode, const float* eps, uint64_t seed, int dtype, void* wpack, hipStream_t s);
+int launch_philox_eps(uint64_t seed, int64_t g_begin, int pair_count, int F, float* eps, hipStream_t s);
+int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count,
+                       const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, float keep_scale, float* Y, int64_t ldY,
+                       hipStream_t s);
+int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
+                        float* Y, int64_t ldY, hipStream_t s);
+int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
+                         double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s);
+int launch_set_edges(int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins, float range_sigmas,
+                     float* lo, float* inv_w, hipStream_t s);
+int launch_finalize(int64_t n_rows, int64_t n, const double* sum, const double* sumsq, const uint16_t* hist,
+                    const float* lo, const float* inv_w, int nbins, const double* q_levels, int n_q, float* mean,
+                    float* std, float* quant, hipStream_t s);
+int launch_loss_stats(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, double* stats, hipStream_t s);
+int launch_loss_forward(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total,
+                        const double* stats, float alpha, float beta, double* part, hipStream_t s);
+int launch_loss_backward(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total,
+                         const double* stats, const double* part, float alpha, float beta, float grad_scale,
+                         float* grad, hipStream_t s);
+
+}  // namespace mcmc

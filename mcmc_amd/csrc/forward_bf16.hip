@@ -1,0 +1,156 @@
+// bf16 fused forward of BayesianNetwork for (member,sample) pairs - the throughput path.
+//
+// Restates /root/reference/models/bayesian_ensemble.py:73-92 in eval mode (what predict() runs,
+// :215-216: dropout is the identity) on pre-sampled effective weights.  One workgroup = one
+// pair x one row superblock; its 8 waves (2 per SIMD) keep the pair's 89 KB of bf16 weight
+// fragments resident in LDS and stream 32-row tiles past them:
+//     Z^T[out, batch] = W[out, k] . H^T[k, batch]          v_mfma_f32_32x32x16_bf16
+// The accumulator of one layer (feature f(i,h) in register i, batch row on the lane) is
+// converted to bf16 in place and IS the next layer's B operand - activations never touch LDS or
+// HBM; only A fragments (weights, pre-permuted by sample_weights.hip) are read from LDS, one
+// ds_read_b128 per MFMA.  88 MFMAs per 32 rows = 45,056 MAC/row for 43,840 algorithmic (97.3 %).
+//
+// ELU runs in the log2e-scaled domain (layout.hpp): a = log2e*z,
+//     phi(a) = max(a, log2e * 2^min(a,0) - log2e) = log2e * elu(z)
+// = v_exp_f32 (clamp) + v_fma_f32 + v_max_f32 per element, the budget that keeps the VALU under
+// the MFMA time at 2 waves per SIMD.
+#include "common.hpp"
+
+namespace mcmc {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr int kWaves = 8;
+constexpr int kMaxK0Steps = 2;  // input_dim + 1 <= 32
+
+__device__ __forceinline__ float phi(float a) {
+    // 2^min(a,0): the clamp folds into v_exp_f32's output modifier
+    const float t = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a), 0.0f, 1.0f);
+    const float e = fmaf(t, kLog2e, -kLog2e);
+    // plain fmaxf makes hipcc canonicalise the MFMA output first (a second v_max per element)
+    float o;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(e));
+    return o;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& acc, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)phi(acc[8 * s + j]);
+    return o;
+}
+
+__global__ __launch_bounds__(64 * kWaves, 2) void forward_bf16_kernel(const unsigned short* __restrict__ xpack,
+                                                                      int64_t n_rows, int F, int rows_per_block,
+                                                                      const unsigned char* __restrict__ wpack,
+                                                                      float* __restrict__ Y, int64_t ldY) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const WPackBF16 L(F);
+    const int ks0 = L.K0 / 16;
+    const int c = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    {  // stage this pair's fragments: linear 16-B copy (the image is already lane-linear)
+        const uint4* src = reinterpret_cast<const uint4*>(wpack + (int64_t)c * L.total);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = threadIdx.x; i < (int)(L.total / 16); i += 64 * kWaves) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const bf16x8* A0 = reinterpret_cast<const bf16x8*>(lds + L.l0) + lane;
+    const bf16x8* A1 = reinterpret_cast<const bf16x8*>(lds + L.l1) + lane;
+    const bf16x8* A2 = reinterpret_cast<const bf16x8*>(lds + L.l2) + lane;
+    const float* B1 = reinterpret_cast<const float*>(lds + L.b1) + h * 16;
+    const float* B2 = reinterpret_cast<const float*>(lds + L.b2) + h * 16;
+    const float* W3 = reinterpret_cast<const float*>(lds + L.w3) + h * 16;
+    const float b3 = *reinterpret_cast<const float*>(lds + L.b3);
+
+    const int64_t padded = rows_pad(n_rows);
+    const int64_t blk_begin = (int64_t)blockIdx.x * rows_per_block;
+    int64_t blk_end = blk_begin + rows_per_block;
+    if (blk_end > padded) blk_end = padded;
+
+    for (int64_t row0 = blk_begin + 32 * wave; row0 < blk_end; row0 += 32 * kWaves) {
+        const int64_t row = row0 + r;
+        // the weight image is loop-invariant: without this the compiler hoists all 88 A
+        // fragments (352 VGPRs) out of the tile loop and spills
+        asm volatile("" ::: "memory");
+        bf16x8 xb[kMaxK0Steps];
+#pragma unroll
+        for (int s = 0; s < kMaxK0Steps; ++s)
+            if (s < ks0) xb[s] = *reinterpret_cast<const bf16x8*>(xpack + row * L.K0 + 16 * s + 8 * h);
+
+        // ---- layer 0: input_dim(+1) -> 256 ----
+        bf16x8 hb1[16];
+#pragma unroll
+        for (int mo = 0; mo < 8; ++mo) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int s = 0; s < kMaxK0Steps; ++s)
+                if (s < ks0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[(mo * ks0 + s) * 64], xb[s], acc, 0, 0, 0);
+            hb1[2 * mo] = pack8(acc, 0);
+            hb1[2 * mo + 1] = pack8(acc, 1);
+        }
+        // ---- layer 1: 256 -> 128 ----
+        bf16x8 hb2[8];
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = B1[mo * 32 + i];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[(mo * 16 + s) * 64], hb1[s], acc, 0, 0, 0);
+            hb2[2 * mo] = pack8(acc, 0);
+            hb2[2 * mo + 1] = pack8(acc, 1);
+        }
+        // ---- layer 2: 128 -> 64, layer 3: 64 -> 1 on the VALU ----
+        float y = 0.0f;
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = B2[mo * 32 + i];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[(mo * 8 + s) * 64], hb2[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) y = fmaf(W3[mo * 32 + i], phi(acc[i]), y);
+        }
+        y += __shfl_xor(y, 32);
+        y += b3;
+        if (h == 0 && row < n_rows) Y[(int64_t)c * ldY + row] = y;
+    }
+}
+
+}  // namespace
+
+int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
+                        float* Y, int64_t ldY, hipStream_t s) {
+    const WPackBF16 L(F);
+    const size_t lds_bytes = (size_t)L.total;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(forward_bf16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_bf16, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+    // Row superblock: large enough that staging 89 KB of weights is ~1 % of its MFMA time
+    // (64 tiles per wave), small enough that pairs x superblocks >> 256 CUs.
+    const int64_t padded = rows_pad(n_rows);
+    int rows_per_block = 32 * kWaves * 64;
+    if (padded < rows_per_block) rows_per_block = (int)((padded + 32 * kWaves - 1) / (32 * kWaves) * (32 * kWaves));
+    const int64_t row_blocks = (padded + rows_per_block - 1) / rows_per_block;
+    for (int done = 0; done < pair_count;) {
+        const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
+        hipLaunchKernelGGL(forward_bf16_kernel, dim3((unsigned)row_blocks, n), dim3(64 * kWaves), lds_bytes, s,
+                           (const unsigned short*)xpack, n_rows, F, rows_per_block,
+                           (const unsigned char*)wpack + (int64_t)done * L.total, Y + (int64_t)done * ldY, ldY);
+        done += n;
+    }
+    (void)ctx;
+    return check_launch("forward_bf16");
+}
+
+}  // namespace mcmc

@@ -1,0 +1,151 @@
+// fp32 fused forward of BayesianNetwork for (member,sample) pairs - the parity path.
+//
+// Restates /root/reference/models/bayesian_ensemble.py:73-92 (3 x {linear, ELU, dropout}, then
+// linear 64->1) on pre-sampled effective weights (sample_weights.hip).  One workgroup = one pair
+// x 128 rows; one wave = 32 rows.  The whole chain stays in registers:
+//     Z^T[out, batch] = W[out, k] . H^T[k, batch]      (v_mfma_f32_32x32x2_f32, exact fp32 FMAs)
+// leaves feature f(i,h) of each 32-feature tile in accumulator register i, batch row on the
+// lane - exactly the B operand of the next layer's MFMA, whose weights sample_weights.hip stored
+// with the matching k permutation.  Weights are staged through LDS in two phases
+// (L0+L1+b1 = 141 KB, then L2+b2+w3+b3 = 33 KB) because fp32 weights (177 KB) exceed the CU's
+// 160 KB.  Dropout keep-masks (train mode) are applied in the activation epilogue.
+#include "common.hpp"
+
+namespace mcmc {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expm1f(x); }
+
+__device__ __forceinline__ void stage(float* lds, const float* __restrict__ src, int64_t n_floats) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(lds);
+    for (int64_t i = threadIdx.x; i < n_floats / 4; i += blockDim.x) d4[i] = s4[i];
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256, 1) void forward_f32_kernel(const float* __restrict__ xpack, int64_t n_rows, int F,
+                                                             const float* __restrict__ wpack, const uint8_t* __restrict__ m0,
+                                                             const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                                                             float keep_scale, float* __restrict__ Y, int64_t ldY) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const WPackF32 L(F);
+    const int ks0 = L.K0 / 2;
+    const int c = blockIdx.y;
+    const float* wp = wpack + (int64_t)c * L.total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 128 + 32 * wave;
+    const int64_t row = row0 + r;
+    const bool active = row0 < rows_pad(n_rows);  // wave-uniform
+    const bool real_row = row < n_rows;
+
+    stage(lds, wp, L.l2);  // L0, L1, B1
+    __syncthreads();
+
+    float h1[8][16];
+    float h2[4][16];
+    if (active) {
+        // ---- layer 0: K0/2 k-steps, bias rides on the 1.0 column of xpack ----
+        float xv[kMaxInputDim / 2 + 1];
+#pragma unroll
+        for (int i = 0; i < kMaxInputDim / 2 + 1; ++i) xv[i] = i < ks0 ? xpack[row * L.K0 + 2 * i + h] : 0.0f;
+#pragma unroll
+        for (int mo = 0; mo < 8; ++mo) {
+            f32x16 acc = {0};
+#pragma unroll
+            for (int i = 0; i < kMaxInputDim / 2 + 1; ++i)
+                if (i < ks0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L.l0 + (mo * ks0 + i) * 64 + lane], xv[i], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = elu1(acc[i]);
+                if (MASKED && real_row) {
+                    const int feat = 32 * mo + acc_feature(i, h);
+                    v = v * (float)m0[((int64_t)c * n_rows + row) * H1 + feat] * keep_scale;
+                }
+                h1[mo][i] = v;
+            }
+        }
+        // ---- layer 1: 128 k-steps per 32-feature output tile ----
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo) {
+            f32x16 acc;
+            const float* bias = lds + L.b1 + (mo * 2 + h) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = bias[i];
+            const float* a = lds + L.l1 + (int64_t)mo * 128 * 64 + lane;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(mt * 16 + i) * 64], h1[mt][i], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = elu1(acc[i]);
+                if (MASKED && real_row) {
+                    const int feat = 32 * mo + acc_feature(i, h);
+                    v = v * (float)m1[((int64_t)c * n_rows + row) * H2 + feat] * keep_scale;
+                }
+                h2[mo][i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    stage(lds, wp + L.l2, L.total - L.l2);  // L2, B2, W3, B3 now at offset 0
+    __syncthreads();
+    if (!active) return;
+
+    const int64_t o_b2 = L.b2 - L.l2, o_w3 = L.w3 - L.l2, o_b3 = L.b3 - L.l2;
+    float y = 0.0f;
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo) {
+        f32x16 acc;
+        const float* bias = lds + o_b2 + (mo * 2 + h) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bias[i];
+        const float* a = lds + (int64_t)mo * 64 * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(mt * 16 + i) * 64], h2[mt][i], acc, 0, 0, 0);
+        const float* w3 = lds + o_w3 + (mo * 2 + h) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = elu1(acc[i]);
+            if (MASKED && real_row) {
+                const int feat = 32 * mo + acc_feature(i, h);
+                v = v * (float)m2[((int64_t)c * n_rows + row) * H3 + feat] * keep_scale;
+            }
+            y = fmaf(w3[i], v, y);
+        }
+    }
+    y += __shfl_xor(y, 32);
+    y += lds[o_b3];
+    if (h == 0 && real_row) Y[(int64_t)c * ldY + row] = y;
+}
+
+}  // namespace
+
+int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count, const uint8_t* m0,
+                       const uint8_t* m1, const uint8_t* m2, float keep_scale, float* Y, int64_t ldY, hipStream_t s) {
+    const WPackF32 L(F);
+    const size_t lds_bytes = (size_t)L.l2 * sizeof(float);
+    const bool masked = m0 != nullptr;
+    auto kern = masked ? forward_f32_kernel<true> : forward_f32_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_f32, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+    const int64_t row_blocks = (rows_pad(n_rows) + 127) / 128;
+    for (int done = 0; done < pair_count;) {
+        const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
+        const int64_t mask_pair = n_rows;  // masks advance by n_rows * width per pair
+        hipLaunchKernelGGL(kern, dim3((unsigned)row_blocks, n), dim3(256), lds_bytes, s, xpack, n_rows, F,
+                           wpack + (int64_t)done * L.total, masked ? m0 + (int64_t)done * mask_pair * H1 : nullptr,
+                           masked ? m1 + (int64_t)done * mask_pair * H2 : nullptr,
+                           masked ? m2 + (int64_t)done * mask_pair * H3 : nullptr, keep_scale, Y + (int64_t)done * ldY, ldY);
+        done += n;
+    }
+    return check_launch("forward_f32");
+}
+
+}  // namespace mcmc

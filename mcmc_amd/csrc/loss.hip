@@ -1,0 +1,188 @@
+// Piece 3: fused peak-weighted loss, forward + closed-form backward (HBM-bound).
+//
+// Restates peak_weighted_loss (/root/reference/utils.py:7-28):
+//   d = p - t;  m = mean(t);  s = std(t) (unbiased);  k = [t > m + beta*s]   (no grad)
+//   e = |d|;  g = sigmoid(e - mean(e));  w = 1 + (alpha-1) k (1+g);  L = mean(d^2 w)
+// and its autograd gradient in closed form:
+//   dL/dp_j = (1/N) [ 2 d_j w_j + (alpha-1) sign(d_j) (k_j d_j^2 g'_j - G/N) ],  g' = g(1-g),
+//   G = sum_i k_i d_i^2 g'_i      (the mean(e) inside the sigmoid carries gradient, utils.py:23)
+// The reference runs ~12 elementwise/reduce kernels forward plus autograd backward; here three
+// streaming passes, each reading p,t once with 16-B loads.  The global sums sit in device
+// memory (fp64) between passes so that data-parallel ranks can all-reduce them.
+#include "common.hpp"
+
+namespace mcmc {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_accumulate(double (&v)[NV], double* __restrict__ out) {
+    __shared__ double sm[NV][kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double w = wave_sum(v[i]);
+        if (lane == 0) sm[i][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) a += sm[threadIdx.x][w];
+        atomicAdd(out + threadIdx.x, a);  // global_atomic_add_f64
+    }
+}
+
+struct LossConsts {
+    float thr;     // m + beta*s   (NaN when N == 1: k == 0 everywhere, plain MSE)
+    float mean_e;  // mean |p-t|
+    float am1;     // alpha - 1
+};
+
+__device__ __forceinline__ LossConsts loss_consts(const double* __restrict__ stats, double N, float alpha, float beta) {
+    const double st = stats[0], stt = stats[1], se = stats[2];
+    const double m = st / N;
+    const double var = (stt - st * st / N) / (N - 1.0);  // N == 1 -> 0/0 = NaN like torch.std
+    const double s = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
+    LossConsts c;
+    c.thr = (float)(m + (double)beta * s);
+    c.mean_e = (float)(se / N);
+    c.am1 = alpha - 1.0f;
+    return c;
+}
+
+// per-element terms shared by forward and backward
+__device__ __forceinline__ void elem_terms(float p, float t, const LossConsts& c, float& d, float& w, float& kd2gp) {
+    d = p - t;
+    const float e = fabsf(d);
+    const float k = t > c.thr ? 1.0f : 0.0f;
+    const float g = 1.0f / (1.0f + expf(c.mean_e - e));
+    w = 1.0f + c.am1 * k * (1.0f + g);
+    kd2gp = k * d * d * g * (1.0f - g);
+}
+
+__global__ __launch_bounds__(kBlock) void loss_stats_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                            double* __restrict__ stats) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    const int64_t n4 = n / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        const float4 a = p4[i], b = t4[i];
+        const float pv[4] = {a.x, a.y, a.z, a.w}, tv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double td = (double)tv[u];
+            acc[0] += td;
+            acc[1] = fma(td, td, acc[1]);
+            acc[2] += (double)fabsf(pv[u] - tv[u]);
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double td = (double)t[i];
+        acc[0] += td;
+        acc[1] = fma(td, td, acc[1]);
+        acc[2] += (double)fabsf(p[i] - t[i]);
+    }
+    block_accumulate<3>(acc, stats);
+}
+
+__global__ __launch_bounds__(kBlock) void loss_forward_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                              double N, const double* __restrict__ stats, float alpha, float beta,
+                                                              double* __restrict__ part) {
+    const LossConsts c = loss_consts(stats, N, alpha, beta);
+    double acc[2] = {0.0, 0.0};
+    const int64_t n4 = n / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        const float4 a = p4[i], b = t4[i];
+        const float pv[4] = {a.x, a.y, a.z, a.w}, tv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float d, w, q;
+            elem_terms(pv[u], tv[u], c, d, w, q);
+            acc[0] += (double)(d * d * w);
+            acc[1] += (double)q;
+        }
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float d, w, q;
+        elem_terms(p[i], t[i], c, d, w, q);
+        acc[0] += (double)(d * d * w);
+        acc[1] += (double)q;
+    }
+    block_accumulate<2>(acc, part);
+}
+
+__device__ __forceinline__ float grad_elem(float p, float t, const LossConsts& c, float g_over_n, float scale) {
+    float d, w, q;
+    elem_terms(p, t, c, d, w, q);
+    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return scale * (2.0f * d * w + c.am1 * sgn * (q - g_over_n));
+}
+
+__global__ __launch_bounds__(kBlock) void loss_backward_kernel(const float* __restrict__ p, const float* __restrict__ t, int64_t n,
+                                                               double N, const double* __restrict__ stats,
+                                                               const double* __restrict__ part, float alpha, float beta,
+                                                               float grad_scale, float* __restrict__ grad) {
+    const LossConsts c = loss_consts(stats, N, alpha, beta);
+    const float g_over_n = (float)(part[1] / N);
+    const float scale = (float)((double)grad_scale / N);
+    const int64_t n4 = n / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const float4* t4 = reinterpret_cast<const float4*>(t);
+    float4* g4 = reinterpret_cast<float4*>(grad);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+        const float4 a = p4[i], b = t4[i];
+        float4 o;
+        o.x = grad_elem(a.x, b.x, c, g_over_n, scale);
+        o.y = grad_elem(a.y, b.y, c, g_over_n, scale);
+        o.z = grad_elem(a.z, b.z, c, g_over_n, scale);
+        o.w = grad_elem(a.w, b.w, c, g_over_n, scale);
+        g4[i] = o;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        grad[i] = grad_elem(p[i], t[i], c, g_over_n, scale);
+}
+
+inline int loss_grid(const mcmc_ctx* ctx, int64_t n) {
+    int64_t b = (n / 4 + kBlock - 1) / kBlock;
+    const int64_t cap = (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256) * 8;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+int launch_loss_stats(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, double* stats, hipStream_t s) {
+    hipLaunchKernelGGL(loss_stats_kernel, dim3(loss_grid(ctx, n)), dim3(kBlock), 0, s, p, t, n, stats);
+    return check_launch("loss_stats");
+}
+
+int launch_loss_forward(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total, const double* stats,
+                        float alpha, float beta, double* part, hipStream_t s) {
+    hipLaunchKernelGGL(loss_forward_kernel, dim3(loss_grid(ctx, n)), dim3(kBlock), 0, s, p, t, n, (double)n_total, stats, alpha, beta,
+                       part);
+    return check_launch("loss_forward");
+}
+
+int launch_loss_backward(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, int64_t n_total, const double* stats,
+                         const double* part, float alpha, float beta, float grad_scale, float* grad, hipStream_t s) {
+    hipLaunchKernelGGL(loss_backward_kernel, dim3(loss_grid(ctx, n)), dim3(kBlock), 0, s, p, t, n, (double)n_total, stats, part, alpha,
+                       beta, grad_scale, grad);
+    return check_launch("loss_backward");
+}
+
+}  // namespace mcmc

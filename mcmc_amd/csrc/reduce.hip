@@ -1,0 +1,251 @@
+// Piece 2: streaming per-timestep statistics of the MC samples (HBM-bound).
+//
+// Replaces torch.stack/reshape + mean(0) + std(0) of GPUBayesianEnsemble.predict
+// (/root/reference/models/bayesian_ensemble.py:234-246), which materialises all M*S samples
+// ([M*S, B] fp32 = 120 GB at config 3) and reads them twice.  Here a bounded chunk Y[C pairs, B]
+// is consumed once: per row (sum, sum of squares) in fp64 plus a per-row histogram that yields
+// interval quantiles (an extension; the reference computes none - its oracle is torch.quantile).
+//
+// update: workgroup = 64 rows x 4 waves; wave w takes pairs c = w, w+4, ...; lane = row, so a
+//   wave-load is 256 contiguous bytes.  Histogram counts go to an LDS tile with ds_add_u32 on
+//   packed uint16 pairs (row-rotated so rows falling in the same bin hit different banks), and
+//   are added to the global uint16 histogram once per chunk - the tile owns its rows, so global
+//   state is updated without atomics and the result is bitwise deterministic.
+#include "common.hpp"
+
+namespace mcmc {
+
+namespace {
+
+constexpr int kRows = 64;   // rows per workgroup
+constexpr int kWavesR = 4;  // waves per workgroup
+constexpr int kUnroll = 8;  // independent loads in flight per lane
+
+__device__ __forceinline__ int hist_bin(float y, float lo, float inv_w, int nbins) {
+    // fp32, two roundings (no fma) so the CPU restatement bins identically
+    float t = __fmul_rn(__fsub_rn(y, lo), inv_w);
+    t = fminf(fmaxf(t, -1.0f), (float)(nbins - 2));  // NaN -> -1 (fmaxf returns the non-NaN)
+    return (int)floorf(t) + 1;
+}
+
+template <bool HIST>
+__global__ __launch_bounds__(kRows * kWavesR) void reduce_update_kernel(const float* __restrict__ Y, int64_t ldY, int n_pairs,
+                                                                       int64_t n_rows, double* __restrict__ sum,
+                                                                       double* __restrict__ sumsq,
+                                                                       const float* __restrict__ lo_g,
+                                                                       const float* __restrict__ inv_w_g,
+                                                                       uint32_t* __restrict__ hist, int nbins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* red = reinterpret_cast<double*>(smem);                                    // [2][kWavesR][kRows]
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem + 2 * kWavesR * kRows * sizeof(double));  // [kRows][nbins/2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * kRows + lane;
+    const bool live = row < n_rows;
+    const int words = nbins >> 1;  // uint32 words per row (power of two: nbins is 64..512)
+
+    float lo = 0.0f, inv_w = 0.0f;
+    if (HIST) {
+        for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) lh[i] = 0u;
+        if (live) {
+            lo = lo_g[row];
+            inv_w = inv_w_g[row];
+        }
+        __syncthreads();
+    }
+
+    double s1 = 0.0, s2 = 0.0;
+    const float* yp = Y + row;
+    int c = wave;
+    for (; c + (kUnroll - 1) * kWavesR < n_pairs; c += kUnroll * kWavesR) {
+        float v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = live ? __builtin_nontemporal_load(yp + (int64_t)(c + u * kWavesR) * ldY) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const double d = (double)v[u];
+            s1 += d;
+            s2 = fma(d, d, s2);
+            if (HIST && live) {
+                const int b = hist_bin(v[u], lo, inv_w, nbins);
+                atomicAdd(&lh[lane * words + (((b >> 1) + lane) & (words - 1))], 1u << ((b & 1) * 16));
+            }
+        }
+    }
+    for (; c < n_pairs; c += kWavesR) {
+        const float v = live ? __builtin_nontemporal_load(yp + (int64_t)c * ldY) : 0.0f;
+        const double d = (double)v;
+        s1 += d;
+        s2 = fma(d, d, s2);
+        if (HIST && live) {
+            const int b = hist_bin(v, lo, inv_w, nbins);
+            atomicAdd(&lh[lane * words + (((b >> 1) + lane) & (words - 1))], 1u << ((b & 1) * 16));
+        }
+    }
+
+    red[wave * kRows + lane] = s1;
+    red[(kWavesR + wave) * kRows + lane] = s2;
+    __syncthreads();
+    if (wave == 0 && live) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesR; ++w) {  // fixed order: deterministic
+            a += red[w * kRows + lane];
+            b += red[(kWavesR + w) * kRows + lane];
+        }
+        sum[row] += a;
+        sumsq[row] += b;
+    }
+    if (HIST) {
+        // global uint16 counts, two per word; no carry can cross the halves while every count
+        // stays <= 65535 (the caller bounds total samples per row)
+        const int64_t row_base = (int64_t)blockIdx.x * kRows;
+        for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) {
+            const int rl = i / words, w = i & (words - 1);
+            if (row_base + rl < n_rows) {
+                const uint32_t add = lh[rl * words + ((w + rl) & (words - 1))];
+                if (add) hist[(row_base + rl) * words + w] += add;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void set_edges_kernel(int64_t n_rows, double n0, const double* __restrict__ sum,
+                                                        const double* __restrict__ sumsq, int nbins, double range_sigmas,
+                                                        float* __restrict__ lo, float* __restrict__ inv_w) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const double s1 = sum[row], s2 = sumsq[row];
+    const double mean = s1 / n0;
+    const double denom = n0 > 1.0 ? n0 - 1.0 : 1.0;
+    double var = (s2 - s1 * s1 / n0) / denom;
+    if (!(var > 0.0)) var = 0.0;
+    double half = range_sigmas * sqrt(var);
+    double tiny = fabs(mean) * 1e-6;
+    if (tiny < 1e-12) tiny = 1e-12;
+    if (!(half > tiny)) half = tiny;
+    lo[row] = (float)(mean - half);
+    inv_w[row] = (float)((double)(nbins - 2) / (2.0 * half));
+}
+
+struct QLevels {
+    double q[8];
+    int n;
+};
+
+// one wave per row: lane holds K = nbins/64 consecutive bins
+template <int K>
+__global__ __launch_bounds__(256) void finalize_kernel(int64_t n_rows, double n, const double* __restrict__ sum,
+                                                       const double* __restrict__ sumsq, const uint16_t* __restrict__ hist,
+                                                       const float* __restrict__ lo_g, const float* __restrict__ inv_w_g,
+                                                       QLevels ql, float* __restrict__ mean_o, float* __restrict__ std_o,
+                                                       float* __restrict__ quant) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int nbins = K * 64;
+    for (int64_t row = wave_global; row < n_rows; row += n_waves) {
+        if (lane == 0) {
+            const double s1 = sum[row], s2 = sumsq[row];
+            const double m = s1 / n;
+            mean_o[row] = (float)m;
+            double sd;
+            if (n > 1.0) {
+                double var = (s2 - s1 * s1 / n) / (n - 1.0);
+                if (!(var > 0.0)) var = 0.0;
+                sd = sqrt(var);
+            } else {
+                sd = __builtin_nan("");  // torch.std of one sample (bayesian_ensemble.py:246)
+            }
+            std_o[row] = (float)sd;
+        }
+        if (ql.n == 0) continue;
+        uint32_t cnt[K], cum[K];
+        uint32_t tot = 0;
+        const uint16_t* hp = hist + row * nbins + lane * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            cnt[k] = hp[k];
+            tot += cnt[k];
+            cum[k] = tot;
+        }
+        uint32_t incl = tot;  // inclusive scan of lane totals
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const uint32_t excl = incl - tot;
+        const double lo = (double)lo_g[row];
+        const double width = 1.0 / (double)inv_w_g[row];
+        for (int qi = 0; qi < ql.n; ++qi) {
+            const double pos = ql.q[qi] * (n - 1.0);
+            // first bin whose inclusive cumulative count exceeds pos
+            int kk = -1;
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k)
+                if ((double)(excl + cum[k]) > pos) kk = k;
+            const unsigned long long ball = __ballot(kk >= 0);
+            const int first = ball ? __ffsll((long long)ball) - 1 : 63;
+            if (lane == first) {
+                if (kk < 0) kk = K - 1;  // pos beyond all counts (cannot happen when hist sums to n)
+                const int b = lane * K + kk;
+                const double prev = (double)(excl + (kk > 0 ? cum[kk - 1] : 0u));
+                const double cb = (double)(cnt[kk] > 0 ? cnt[kk] : 1u);
+                double val = lo + ((double)(b - 1) + (pos + 0.5 - prev) / cb) * width;
+                if (b == 0) val = lo;
+                if (b == nbins - 1) val = lo + (double)(nbins - 2) * width;
+                quant[(int64_t)qi * n_rows + row] = (float)val;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
+                         double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s) {
+    (void)ctx;
+    const int64_t blocks = (n_rows + kRows - 1) / kRows;
+    const size_t red_bytes = 2 * kWavesR * kRows * sizeof(double);
+    if (hist) {
+        const size_t lds = red_bytes + (size_t)kRows * (nbins / 2) * sizeof(uint32_t);
+        hipLaunchKernelGGL(reduce_update_kernel<true>, dim3((unsigned)blocks), dim3(kRows * kWavesR), lds, s, Y, ldY, n_pairs,
+                           n_rows, sum, sumsq, lo, inv_w, reinterpret_cast<uint32_t*>(hist), nbins);
+    } else {
+        hipLaunchKernelGGL(reduce_update_kernel<false>, dim3((unsigned)blocks), dim3(kRows * kWavesR), red_bytes, s, Y, ldY,
+                           n_pairs, n_rows, sum, sumsq, nullptr, nullptr, nullptr, 0);
+    }
+    return check_launch("reduce_update");
+}
+
+int launch_set_edges(int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins, float range_sigmas,
+                     float* lo, float* inv_w, hipStream_t s) {
+    hipLaunchKernelGGL(set_edges_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, n_rows, (double)n0, sum, sumsq,
+                       nbins, (double)range_sigmas, lo, inv_w);
+    return check_launch("reduce_set_edges");
+}
+
+int launch_finalize(int64_t n_rows, int64_t n, const double* sum, const double* sumsq, const uint16_t* hist, const float* lo,
+                    const float* inv_w, int nbins, const double* q_levels, int n_q, float* mean, float* std, float* quant,
+                    hipStream_t s) {
+    QLevels ql;
+    ql.n = n_q;
+    for (int i = 0; i < 8; ++i) ql.q[i] = i < n_q ? q_levels[i] : 0.0;
+    int64_t blocks = (n_rows + 3) / 4;  // 4 waves per block, one row per wave per trip
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+#define MCMC_FIN(K)                                                                                                         \
+    hipLaunchKernelGGL(finalize_kernel<K>, dim3((unsigned)blocks), dim3(256), 0, s, n_rows, (double)n, sum, sumsq, hist, lo, \
+                       inv_w, ql, mean, std, quant)
+    switch (n_q ? nbins : 64) {
+        case 64: MCMC_FIN(1); break;
+        case 128: MCMC_FIN(2); break;
+        case 256: MCMC_FIN(4); break;
+        case 512: MCMC_FIN(8); break;
+        default: return set_error(MCMC_EINVAL, "nbins must be 64, 128, 256 or 512 (got %d)", nbins);
+    }
+#undef MCMC_FIN
+    return check_launch("reduce_finalize");
+}
+
+}  // namespace mcmc
