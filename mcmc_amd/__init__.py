@@ -1,0 +1,12 @@
+"""mcmc_amd - MI355X-native Monte Carlo predictive path of the fintkz/mcmc Bayesian ensemble.
+
+Only what the path needs: the C-ABI library (csrc/ -> lib/libmcmc_hip.so), its ctypes binding
+(_lib), the chunk-loop driver (engine) and the mirror of the reference's Python interface
+(bayesian_ensemble, loss).  See DESIGN.md and INTEGRATION.md.
+"""
+from .bayesian_ensemble import BayesianLinear, BayesianNetwork, GPUBayesianEnsemble
+from .engine import PredictResult, mc_predict, pack_members
+from .loss import peak_weighted_loss
+
+__all__ = ["BayesianLinear", "BayesianNetwork", "GPUBayesianEnsemble", "PredictResult", "mc_predict", "pack_members",
+           "peak_weighted_loss"]

@@ -1,0 +1,121 @@
+"""ctypes binding of libmcmc_hip.so (include/mcmc_hip.h).
+
+The library is the product: there is no CPU fallback.  A missing or unloadable library, or a
+missing symbol, raises ``MCMCLibraryError`` at first use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmcmc_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
+ABI_VERSION = 1
+
+
+class MCMCLibraryError(RuntimeError):
+    """libmcmc_hip.so missing / wrong ABI (build it: ``make`` or ``__graft_entry__.build()``)."""
+
+
+class MCMCError(RuntimeError):
+    """A libmcmc_hip call returned a negative code."""
+
+
+_ctx_p = C.c_void_p
+_stream = C.c_void_p
+_ptr = C.c_void_p
+_i64, _i32, _u64, _f32 = C.c_int64, C.c_int, C.c_uint64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/mcmc_hip.h declares
+SIGNATURES = {
+    "mcmc_last_error": (C.c_char_p, []),
+    "mcmc_abi_version": (_i32, []),
+    "mcmc_ctx_create": (_i32, [_i32, C.POINTER(_ctx_p)]),
+    "mcmc_ctx_destroy": (_i32, [_ctx_p]),
+    "mcmc_param_count": (_i64, [_i32]),
+    "mcmc_xpack_bytes": (_i64, [_i64, _i32, _i32]),
+    "mcmc_wpack_bytes": (_i64, [_i32, _i32]),
+    "mcmc_pack_x": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _ptr, _stream]),
+    "mcmc_sample_weights": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i32, _i64, _i32, _i32, _ptr, _u64, _i32, _ptr, _stream]),
+    "mcmc_philox_eps": (_i32, [_ctx_p, _u64, _i64, _i32, _i32, _ptr, _stream]),
+    "mcmc_forward": (_i32, [_ctx_p, _i32, _ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _stream]),
+    "mcmc_reduce_update": (_i32, [_ctx_p, _ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _stream]),
+    "mcmc_reduce_set_edges": (_i32, [_ctx_p, _i64, _i64, _ptr, _ptr, _i32, _f32, _ptr, _ptr, _stream]),
+    "mcmc_reduce_finalize": (_i32, [_ctx_p, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, C.POINTER(C.c_double), _i32,
+                                    _ptr, _ptr, _ptr, _stream]),
+    "mcmc_loss_stats": (_i32, [_ctx_p, _ptr, _ptr, _i64, _ptr, _stream]),
+    "mcmc_loss_forward": (_i32, [_ctx_p, _ptr, _ptr, _i64, _i64, _ptr, _f32, _f32, _ptr, _stream]),
+    "mcmc_loss_backward": (_i32, [_ctx_p, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _f32, _f32, _f32, _ptr, _stream]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load the shared library once and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MCMCLibraryError(f"{LIB_PATH} not found - build it with `make` (hipcc, gfx950); there is no CPU fallback")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise MCMCLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise MCMCLibraryError(f"{LIB_PATH} lacks symbol {name}") from e
+            fn.restype, fn.argtypes = res, args
+        if lib.mcmc_abi_version() != ABI_VERSION:
+            raise MCMCLibraryError(f"ABI mismatch: library {lib.mcmc_abi_version()}, binding {ABI_VERSION}")
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    return load().mcmc_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        msg = last_error()
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise MCMCError(f"{what} failed ({rc}): {msg}")
+    return rc
+
+
+class Context:
+    """One per device (include/mcmc_hip.h: mcmc_ctx_create). Not thread-safe."""
+
+    _cache = {}
+
+    def __init__(self, device_index: int):
+        self.lib = load()
+        self.device_index = device_index
+        h = _ctx_p()
+        check(self.lib.mcmc_ctx_create(device_index, C.byref(h)), "mcmc_ctx_create")
+        self.handle = h
+
+    @classmethod
+    def for_device(cls, device_index: int) -> "Context":
+        ctx = cls._cache.get(device_index)
+        if ctx is None:
+            ctx = cls._cache[device_index] = cls(device_index)
+        return ctx
+
+    def close(self):
+        if self.handle:
+            self.lib.mcmc_ctx_destroy(self.handle)
+            self.handle = None

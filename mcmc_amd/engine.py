@@ -1,0 +1,297 @@
+"""Host driver of the MC predictive path: chunk loop over (member, sample) pairs.
+
+Replaces the two Python loops + stack + mean/std of ``GPUBayesianEnsemble.predict``
+(/root/reference/models/bayesian_ensemble.py:221-246) with
+
+    pack_x -> per chunk { sample_weights -> forward -> reduce_update } -> [RCCL combine] -> finalize
+
+All compute is in libmcmc_hip.so (include/mcmc_hip.h); torch only owns device memory, the
+stream and (for world_size > 1) the collective.  There is no CPU path: inputs must live on a
+HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DT_BF16, DT_F32, NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX
+
+HIDDEN = (256, 128, 64)
+_DTYPES = {"fp32": DT_F32, "f32": DT_F32, "float32": DT_F32, torch.float32: DT_F32,
+           "bf16": DT_BF16, "bfloat16": DT_BF16, torch.bfloat16: DT_BF16}
+
+
+def resolve_dtype(dtype) -> int:
+    try:
+        return _DTYPES[dtype]
+    except KeyError:
+        raise ValueError(f"dtype must be 'fp32' or 'bf16', got {dtype!r}") from None
+
+
+def param_count(input_dim: int) -> int:
+    """Noise draws per pair (44,289 at input_dim 11; bayesian_ensemble.py:17-22,61-70)."""
+    n, k = 0, input_dim
+    for h in HIDDEN + (1,):
+        n += k * h + h
+        k = h
+    return n
+
+
+def pack_members(models: Sequence[torch.nn.Module], device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """mu[M,P], rho[M,P] fp32 on ``device`` in the flat layout: per layer W [out,in] row-major
+    then b, layers in forward order (the reference's noise draw order, bayesian_ensemble.py:43-44).
+    Reads the members through the reference's own attribute names (bayesian_ensemble.py:58-70)."""
+    mus, rhos = [], []
+    for m in models:
+        layers = list(m.hidden_layers) + [m.output_layer]
+        mus.append(torch.cat([torch.cat([l.weight_mu.detach().reshape(-1), l.bias_mu.detach().reshape(-1)]) for l in layers]))
+        rhos.append(torch.cat([torch.cat([l.weight_rho.detach().reshape(-1), l.bias_rho.detach().reshape(-1)]) for l in layers]))
+    mu = torch.stack(mus).to(device=device, dtype=torch.float32).contiguous()
+    rho = torch.stack(rhos).to(device=device, dtype=torch.float32).contiguous()
+    return mu, rho
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> int:
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live on a HIP device (got {t.device}); mcmc_amd has no CPU path")
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def shard_pairs(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced q-range of ``rank``: [begin, end)."""
+    base, rem = divmod(n_pairs, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def pair_global_ids(begin: int, count: int, M: int, S: int, device=None) -> torch.Tensor:
+    """Processing index q -> global pair id g = member*S + sample, member = q % M, sample = q // M."""
+    q = torch.arange(begin, begin + count, device=device)
+    return (q % M) * S + q // M
+
+
+@dataclass
+class ReduceState:
+    """Per-row partial statistics (the payload of the multi-GPU combine)."""
+    n: int
+    sum: torch.Tensor                    # [B] fp64
+    sumsq: torch.Tensor                  # [B] fp64
+    hist: Optional[torch.Tensor] = None  # [B, nbins] uint16 counts, stored as int16
+    lo: Optional[torch.Tensor] = None    # [B] fp32
+    inv_w: Optional[torch.Tensor] = None  # [B] fp32
+    nbins: int = 0
+
+
+def combine_partials(state: ReduceState, group=None) -> ReduceState:
+    """Sum-combine the partials of all ranks: fp64 moments and the histogram
+    (uint16 pairs viewed as int32: no carry crosses a half while total counts stay <= 65,535).
+    RCCL over xGMI when the tensors are on GPUs (backend 'nccl'), gloo on CPU tensors in tests."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return state
+    moments = torch.stack([state.sum, state.sumsq])
+    count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
+    dist.all_reduce(moments, group=group)
+    dist.all_reduce(count, group=group)
+    state.sum, state.sumsq = moments[0].contiguous(), moments[1].contiguous()
+    state.n = int(count.item())
+    if state.hist is not None:
+        if state.n > 65535:
+            raise ValueError(f"uint16 histogram holds at most 65,535 samples per row (n = {state.n})")
+        dist.all_reduce(state.hist.view(torch.int32), group=group)
+    return state
+
+
+class Engine:
+    """Thin typed wrapper over the C ABI for one device."""
+
+    def __init__(self, device: torch.device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"mcmc_amd needs a HIP device, got {device}; there is no CPU path")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self.ctx = _lib.Context.for_device(self.device.index)
+        self.lib = self.ctx.lib
+
+    # ---- piece 1 -------------------------------------------------------------------------
+    def pack_x(self, X: torch.Tensor, dtype: int) -> torch.Tensor:
+        B, F = X.shape
+        nbytes = _lib.check(self.lib.mcmc_xpack_bytes(B, F, dtype), "mcmc_xpack_bytes")
+        xp = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.mcmc_pack_x(self.ctx.handle, _p(X), B, F, dtype, _p(xp), _stream()), "mcmc_pack_x")
+        return xp
+
+    def wpack_bytes(self, F: int, dtype: int) -> int:
+        return _lib.check(self.lib.mcmc_wpack_bytes(F, dtype), "mcmc_wpack_bytes")
+
+    def sample_weights(self, mu, rho, S: int, F: int, pair_begin: int, pair_count: int, noise_mode: int,
+                       eps: Optional[torch.Tensor], seed: int, dtype: int, wpack: torch.Tensor):
+        _lib.check(self.lib.mcmc_sample_weights(self.ctx.handle, _p(mu), _p(rho), mu.shape[0], S, F, pair_begin, pair_count,
+                                                noise_mode, _p(eps), seed & 0xFFFFFFFFFFFFFFFF, dtype, _p(wpack), _stream()),
+                   "mcmc_sample_weights")
+
+    def philox_eps(self, seed: int, g_begin: int, pair_count: int, F: int) -> torch.Tensor:
+        eps = torch.empty(pair_count, param_count(F), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mcmc_philox_eps(self.ctx.handle, seed & 0xFFFFFFFFFFFFFFFF, g_begin, pair_count, F, _p(eps), _stream()),
+                   "mcmc_philox_eps")
+        return eps
+
+    def forward(self, dtype: int, xpack, B: int, F: int, wpack, pair_count: int, Y: torch.Tensor, ldY: int,
+                masks=None, keep_scale: float = 1.0):
+        m0 = m1 = m2 = None
+        if masks is not None:
+            m0, m1, m2 = masks
+        _lib.check(self.lib.mcmc_forward(self.ctx.handle, dtype, _p(xpack), B, F, _p(wpack), pair_count, _p(m0), _p(m1), _p(m2),
+                                         keep_scale, _p(Y), ldY, _stream()), "mcmc_forward")
+
+    # ---- piece 2 -------------------------------------------------------------------------
+    def new_state(self, B: int, nbins: int = 0) -> ReduceState:
+        st = ReduceState(0, torch.zeros(B, dtype=torch.float64, device=self.device),
+                         torch.zeros(B, dtype=torch.float64, device=self.device))
+        if nbins:
+            st.nbins = nbins
+            st.hist = torch.zeros(B, nbins, dtype=torch.int16, device=self.device)
+            st.lo = torch.zeros(B, dtype=torch.float32, device=self.device)
+            st.inv_w = torch.zeros(B, dtype=torch.float32, device=self.device)
+        return st
+
+    def reduce_update(self, Y: torch.Tensor, ldY: int, n_pairs: int, B: int, st: ReduceState, with_hist: bool = True):
+        use_hist = with_hist and st.hist is not None
+        _lib.check(self.lib.mcmc_reduce_update(self.ctx.handle, _p(Y), ldY, n_pairs, B, _p(st.sum), _p(st.sumsq),
+                                               _p(st.lo if use_hist else None), _p(st.inv_w if use_hist else None),
+                                               _p(st.hist if use_hist else None), st.nbins if use_hist else 0, _stream()),
+                   "mcmc_reduce_update")
+        st.n += n_pairs
+
+    def set_edges(self, B: int, n0: int, psum, psumsq, st: ReduceState, range_sigmas: float):
+        _lib.check(self.lib.mcmc_reduce_set_edges(self.ctx.handle, B, n0, _p(psum), _p(psumsq), st.nbins, range_sigmas,
+                                                  _p(st.lo), _p(st.inv_w), _stream()), "mcmc_reduce_set_edges")
+
+    def finalize(self, B: int, st: ReduceState, q_levels: Sequence[float] = ()):
+        mean = torch.empty(B, dtype=torch.float32, device=self.device)
+        std = torch.empty(B, dtype=torch.float32, device=self.device)
+        nq = len(q_levels)
+        quant = torch.empty(nq, B, dtype=torch.float32, device=self.device) if nq else None
+        qarr = (C.c_double * max(nq, 1))(*[float(q) for q in q_levels])
+        _lib.check(self.lib.mcmc_reduce_finalize(self.ctx.handle, B, st.n, _p(st.sum), _p(st.sumsq),
+                                                 _p(st.hist if nq else None), _p(st.lo if nq else None),
+                                                 _p(st.inv_w if nq else None), st.nbins, qarr, nq, _p(mean), _p(std), _p(quant),
+                                                 _stream()), "mcmc_reduce_finalize")
+        return mean, std, quant
+
+
+@dataclass
+class PredictResult:
+    mean: torch.Tensor
+    std: torch.Tensor
+    quantiles: Optional[torch.Tensor] = None       # [n_q, B]
+    bin_width: Optional[torch.Tensor] = None       # [B] histogram bin width (quantile resolution)
+    samples: Optional[torch.Tensor] = None         # [M*S, B] in the reference's all_predictions order
+    n_samples: int = 0
+
+
+def default_chunk_pairs(ldY: int, wpack_bytes: int, M: int, device) -> int:
+    """Pairs per chunk: the sample buffer Y[C, ldY] fp32 plus the chunk's packed weights within
+    min(16 GiB, a quarter of free HBM).  MI355X has 288 GB: large chunks keep the histogram's
+    read-modify-write small beside the sample stream."""
+    free, _ = torch.cuda.mem_get_info(device)
+    budget = min(16 << 30, free // 4)
+    c = max(1, budget // (ldY * 4 + wpack_bytes))
+    if c > M:
+        c -= c % M  # whole rounds of members per chunk
+    return int(min(c, 32768))
+
+
+def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples: int, *, dtype="fp32",
+               noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
+               q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
+               chunk_pairs: Optional[int] = None, group=None, return_samples: bool = False) -> PredictResult:
+    """Monte Carlo predictive statistics of the ensemble over X.
+
+    X [B,F] fp32 on a HIP device; mu, rho [M,P] fp32 (pack_members).  noise: 'philox'
+    (counter-based, keyed by seed and the global pair id: independent of chunking and world
+    size), 'injected' (eps [M*S,P] fp32 in the reference's draw order) or 'none' (sample=False).
+    With torch.distributed initialised (backend 'nccl' = RCCL), the M*S pairs are sharded over
+    the ranks of ``group`` and the partial (sum, sumsq, histogram) are combined by all-reduce;
+    every rank returns the full result.
+    """
+    import torch.distributed as dist
+    dev_index = _require_gpu(X, "X")
+    eng = Engine(torch.device("cuda", dev_index))
+    dt = resolve_dtype(dtype)
+    X = X.detach().rename(None).to(torch.float32).contiguous()
+    if X.dim() != 2:
+        raise ValueError(f"X must be [rows, features], got {tuple(X.shape)}")
+    B, F = X.shape
+    M, P = mu.shape
+    if P != param_count(F):
+        raise ValueError(f"Expected {F} input features to give {param_count(F)} parameters per member, got {P}")
+    S = int(num_samples)
+    if S < 1:
+        raise ValueError("num_samples must be >= 1")
+    mode = {"philox": NOISE_PHILOX, "injected": NOISE_INJECTED, "none": NOISE_NONE}.get(noise)
+    if mode is None:
+        raise ValueError(f"noise must be 'philox', 'injected' or 'none', got {noise!r}")
+    if mode == NOISE_INJECTED:
+        if eps is None or tuple(eps.shape) != (M * S, P):
+            raise ValueError(f"injected eps must be [{M * S}, {P}]")
+        _require_gpu(eps, "eps")
+        eps = eps.to(torch.float32).contiguous()
+    N = M * S
+    nq = len(q_levels)
+    if nq and N > 65535:
+        raise ValueError(f"quantile histograms count in uint16: M*S = {N} exceeds 65,535")
+
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    q_begin, q_end = shard_pairs(N, rank, world)
+    n_local = q_end - q_begin
+
+    with torch.cuda.device(eng.device):
+        xpack = eng.pack_x(X, dt)
+        ldY = (B + 63) // 64 * 64
+        wbytes = eng.wpack_bytes(F, dt)
+        Cn = chunk_pairs or default_chunk_pairs(ldY, wbytes, M, eng.device)
+        Cn = max(1, min(Cn, max(n_local, 1)))
+        Y = torch.empty(Cn, ldY, dtype=torch.float32, device=eng.device)
+        wpack = torch.empty(Cn * wbytes, dtype=torch.uint8, device=eng.device)
+        st = eng.new_state(B, nbins if nq else 0)
+        samples = torch.empty(N, B, dtype=torch.float32, device=eng.device) if return_samples else None
+        if return_samples and world > 1:
+            raise ValueError("return_samples is a single-process debugging aid")
+
+        first = True
+        for begin in range(q_begin, q_end, Cn):
+            cnt = min(Cn, q_end - begin)
+            eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
+            eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY)
+            if nq and first:
+                # pilot: the first chunk's moments (all ranks') place every row's histogram
+                pilot = eng.new_state(B)
+                eng.reduce_update(Y, ldY, cnt, B, pilot)
+                pilot = combine_partials(pilot, group)
+                eng.set_edges(B, pilot.n, pilot.sum, pilot.sumsq, st, range_sigmas)
+            first = False
+            eng.reduce_update(Y, ldY, cnt, B, st)
+            if samples is not None:
+                samples[pair_global_ids(begin, cnt, M, S, eng.device)] = Y[:cnt, :B]
+        if nq and first:  # a rank without pairs still joins the pilot combine
+            pilot = combine_partials(eng.new_state(B), group)
+            eng.set_edges(B, max(pilot.n, 1), pilot.sum, pilot.sumsq, st, range_sigmas)
+
+        st = combine_partials(st, group)
+        mean, std, quant = eng.finalize(B, st, q_levels)
+        width = (1.0 / st.inv_w) if nq else None
+    return PredictResult(mean, std, quant, width, samples, st.n)

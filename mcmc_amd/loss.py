@@ -1,0 +1,82 @@
+"""peak_weighted_loss on the fused HIP kernels (mirror of /root/reference/utils.py:7-28).
+
+Same name, argument meaning and defaults as the reference function; differentiable w.r.t.
+``y_pred`` through the closed-form backward.  ``y_true`` gets no gradient
+(the reference's callers never ask for one: bayesian_ensemble.py:176, temporal_fusion.py:251).
+With ``group`` set (torch.distributed, data-parallel over rows) the statistics are global-batch
+like the reference's: three tiny all-reduces (4 + 2 scalars) around the passes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import Engine, _p, _require_gpu, _stream
+
+
+def _is_dist() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _allreduce(t: torch.Tensor, group):
+    """group False: local statistics (reference semantics); None / a group: global-batch."""
+    if group is False or not _is_dist():
+        return
+    import torch.distributed as dist
+    dist.all_reduce(t, group=group)
+
+
+class _PeakWeightedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y_true, alpha, beta, group):
+        dev = _require_gpu(y_pred, "y_pred")
+        _require_gpu(y_true, "y_true")
+        eng = Engine(torch.device("cuda", dev))
+        p = y_pred.detach().to(torch.float32).contiguous().view(-1)
+        t = y_true.detach().to(torch.float32).contiguous().view(-1)
+        if p.data_ptr() % 16:
+            p = p.clone()
+        if t.data_ptr() % 16:
+            t = t.clone()
+        if p.numel() != t.numel():
+            raise ValueError(f"y_pred has {p.numel()} elements, y_true {t.numel()}")
+        n = p.numel()
+        with torch.cuda.device(eng.device):
+            stats = torch.zeros(4, dtype=torch.float64, device=eng.device)
+            stats[3] = n
+            _lib.check(eng.lib.mcmc_loss_stats(eng.ctx.handle, _p(p), _p(t), n, _p(stats), _stream()), "mcmc_loss_stats")
+            _allreduce(stats, group)
+            n_total = int(stats[3].item()) if group is not False and _is_dist() else n
+            part = torch.zeros(4, dtype=torch.float64, device=eng.device)
+            _lib.check(eng.lib.mcmc_loss_forward(eng.ctx.handle, _p(p), _p(t), n, n_total, _p(stats), float(alpha), float(beta),
+                                                 _p(part), _stream()), "mcmc_loss_forward")
+            _allreduce(part, group)
+            loss = (part[0] / n_total).to(torch.float32)
+        ctx.save_for_backward(p, t, stats, part)
+        ctx.meta = (eng, n, n_total, float(alpha), float(beta), y_pred.shape, y_pred.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p, t, stats, part = ctx.saved_tensors
+        eng, n, n_total, alpha, beta, shape, dtype = ctx.meta
+        with torch.cuda.device(eng.device):
+            grad = torch.empty_like(p)
+            # grad_out is a device scalar: fold it in afterwards to avoid a host sync
+            _lib.check(eng.lib.mcmc_loss_backward(eng.ctx.handle, _p(p), _p(t), n, n_total, _p(stats), _p(part), alpha, beta, 1.0,
+                                                  _p(grad), _stream()), "mcmc_loss_backward")
+            grad = (grad * grad_out.to(torch.float32)).view(shape).to(dtype)
+        return grad, None, None, None, None
+
+
+def peak_weighted_loss(y_pred, y_true, alpha=2.0, beta=0.5, *, group=False):
+    """Custom loss function for handling demand spikes (utils.py:7).
+
+    ``group=False`` (default): statistics over this call's tensors, as the reference.
+    ``group=None`` / a process group: rows are sharded over ranks; statistics are global."""
+    y_pred = y_pred.rename(None) if y_pred.has_names() else y_pred
+    y_true = y_true.rename(None) if y_true.has_names() else y_true
+    return _PeakWeightedLoss.apply(y_pred, y_true, alpha, beta, group)

@@ -1,0 +1,279 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors captured from the reference.  Run on the MI355X box: pytest -m gpu.
+
+Tolerances (BASELINE.json north_star): fp32 mean/std within 1e-5 relative - measured against
+max(|mean|, std) because the standardised mean crosses zero (hard part 4);
+bf16 within 2e-2; interval bounds within one histogram bin of torch.quantile.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+Q = (0.025, 0.5, 0.975)
+
+
+def _dev():
+    return torch.device("cuda", 0)
+
+
+def _rel(a, b, scale):
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / scale))
+
+
+def _check_stats(res, mean_ref, std_ref, tol):
+    mean, std = res.mean.cpu().numpy(), res.std.cpu().numpy()
+    scale = np.maximum(np.abs(mean_ref), std_ref).astype(np.float64)
+    assert _rel(mean, mean_ref, scale) <= tol
+    assert _rel(std, std_ref, np.abs(std_ref).astype(np.float64)) <= tol
+
+
+def _run(g, dtype, S, eps, q_levels=Q, **kw):
+    from mcmc_amd import mc_predict
+    d = _dev()
+    X = torch.from_numpy(g["X"]).to(d)
+    mu, rho = torch.from_numpy(g["mu"]).to(d), torch.from_numpy(g["rho"]).to(d)
+    return mc_predict(X, mu, rho, S, dtype=dtype, noise="injected", eps=eps.reshape(-1, eps.shape[-1]).to(d),
+                      q_levels=q_levels, return_samples=True, **kw)
+
+
+@pytest.mark.parametrize("name", ["predict_small.npz", "predict_small_F7.npz", "predict_small_F9.npz"])
+def test_fp32_forward_matches_reference_vectors(golden, name):
+    g = golden(name)
+    eps = torch.from_numpy(g["eps"])
+    S = eps.shape[1]
+    res = _run(g, "fp32", S, eps, q_levels=())
+    ref = g["all_predictions"]
+    got = res.samples.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-5 * max(1.0, np.max(np.abs(ref)))
+    _check_stats(res, g["mean"], g["std"], 1e-5)
+
+
+def test_fp32_config2_mean_std_quantiles(golden):
+    g = golden("predict_cfg1.npz")
+    M, S = int(g["M"]), int(g["S"])
+    eps = orc.reference_rng_eps(int(g["eps_seed"]), M, S, 11)
+    res = _run(g, "fp32", S, eps, nbins=128)
+    got = res.samples.cpu().numpy()
+    assert np.max(np.abs(got[:8] - g["all_predictions_head"])) <= 2e-5
+    assert np.max(np.abs(got[-4:] - g["all_predictions_tail"])) <= 2e-5
+    _check_stats(res, g["mean"], g["std"], 1e-5)
+    width = res.bin_width.cpu().numpy()
+    q = res.quantiles.cpu().numpy()
+    assert np.all(np.abs(q - g["quantiles"]) <= width[None, :])
+    # chunking must not change anything: sums are fp64, histogram integer
+    res2 = _run(g, "fp32", S, eps, nbins=128, chunk_pairs=35)
+    assert torch.equal(res2.mean, res.mean) or _rel(res2.mean.cpu().numpy(), res.mean.cpu().numpy(), 1.0) < 1e-7
+    assert np.all(np.abs(res2.quantiles.cpu().numpy() - g["quantiles"]) <= res2.bin_width.cpu().numpy()[None, :])
+
+
+def test_bf16_config2_within_2e2(golden):
+    g = golden("predict_cfg1.npz")
+    M, S = int(g["M"]), int(g["S"])
+    eps = orc.reference_rng_eps(int(g["eps_seed"]), M, S, 11)
+    res = _run(g, "bf16", S, eps, nbins=128)
+    _check_stats(res, g["mean"], g["std"], 2e-2)
+    width = res.bin_width.cpu().numpy()
+    allp = orc.predict_all(torch.from_numpy(g["X"]), torch.from_numpy(g["mu"]), torch.from_numpy(g["rho"]), eps)
+    got = res.samples.cpu().numpy()
+    scale = float(allp.abs().max())
+    assert np.max(np.abs(got - allp.numpy())) <= 2e-2 * scale
+    # bf16 samples are themselves perturbed: allow the bf16 error on top of one bin
+    assert np.all(np.abs(res.quantiles.cpu().numpy() - g["quantiles"]) <= width[None, :] + 2e-2 * scale)
+
+
+def test_train_mode_masks_fp32(golden):
+    """identical weights + identical injected dropout masks (train-mode forward)."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import Engine
+    g = golden("train_fwd.npz")
+    d = _dev()
+    eng = Engine(d)
+    X = torch.from_numpy(g["X"]).to(d)
+    B, F = X.shape
+    npass = g["eps"].shape[0]
+    mu, rho = torch.from_numpy(g["mu"]).to(d), torch.from_numpy(g["rho"]).to(d)
+    eps = torch.from_numpy(g["eps"]).to(d)  # [npass, P]: M = 1, S = npass -> g = s
+    xp = eng.pack_x(X, _lib.DT_F32)
+    wp = torch.empty(npass * eng.wpack_bytes(F, _lib.DT_F32), dtype=torch.uint8, device=d)
+    eng.sample_weights(mu, rho, npass, F, 0, npass, _lib.NOISE_INJECTED, eps, 0, _lib.DT_F32, wp)
+    ldY = 64
+    Y = torch.zeros(npass, ldY, device=d)
+    masks = [torch.from_numpy(g[f"mask{l}"]).to(d).contiguous() for l in range(3)]
+    keep_scale = float(torch.tensor(1.0 / 0.9, dtype=torch.float32))
+    eng.forward(_lib.DT_F32, xp, B, F, wp, npass, Y, ldY, masks=masks, keep_scale=keep_scale)
+    got = Y[:, :B].cpu().numpy()
+    assert np.max(np.abs(got - g["out"])) <= 1e-5 * max(1.0, np.max(np.abs(g["out"])))
+
+
+def test_philox_noise_matches_oracle():
+    from mcmc_amd.engine import Engine
+    eng = Engine(_dev())
+    seed = 0x1234_5678_9ABC_DEF0
+    got = eng.philox_eps(seed, 5, 3, 11).cpu().numpy()
+    ref = orc.philox_eps(seed, [5, 6, 7], 44289)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 2e-5  # same integer stream; libm vs ocml log/sin/cos differ by ulps
+    assert abs(got.mean()) < 2e-2 and abs(got.std() - 1) < 2e-2
+
+
+def test_philox_predict_matches_oracle_on_same_noise(golden):
+    """MCMC_NOISE_PHILOX end to end: oracle fed with the CPU restatement of the same counters."""
+    from mcmc_amd import mc_predict
+    g = golden("predict_small.npz")
+    d = _dev()
+    X = torch.from_numpy(g["X"])
+    mu, rho = torch.from_numpy(g["mu"]), torch.from_numpy(g["rho"])
+    M, S, seed = mu.shape[0], 5, 99
+    res = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype="fp32", noise="philox", seed=seed, return_samples=True)
+    eps = torch.from_numpy(orc.philox_eps(seed, range(M * S), mu.shape[1])).reshape(M, S, -1)
+    allp = orc.predict_all(X, mu, rho, eps)
+    assert np.max(np.abs(res.samples.cpu().numpy() - allp.numpy())) <= 1e-4
+    m, s = orc.reduce_mean_std(allp)
+    _check_stats(res, m.numpy(), s.numpy(), 1e-4)
+    # bf16 with the same key
+    resb = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype="bf16", noise="philox", seed=seed)
+    _check_stats(resb, m.numpy(), s.numpy(), 2e-2)
+
+
+def test_noise_none_is_deterministic_mean(golden):
+    from mcmc_amd import mc_predict
+    g = golden("predict_small.npz")
+    d = _dev()
+    X, mu, rho = (torch.from_numpy(g[k]) for k in ("X", "mu", "rho"))
+    res = mc_predict(X.to(d), mu.to(d), rho.to(d), 1, dtype="fp32", noise="none", return_samples=True)
+    ref = torch.stack([orc.forward_pair(X, mu[m], rho[m], None) for m in range(mu.shape[0])])
+    assert np.max(np.abs(res.samples.cpu().numpy() - ref.detach().numpy())) <= 1e-5
+
+
+@pytest.mark.parametrize("B", [1, 31, 33, 129, 300])
+def test_ragged_row_counts(golden, B):
+    from mcmc_amd import mc_predict
+    g = golden("predict_small.npz")
+    d = _dev()
+    torch.manual_seed(B)
+    X = torch.randn(B, 11)
+    mu, rho = torch.from_numpy(g["mu"]), torch.from_numpy(g["rho"])
+    eps = torch.from_numpy(g["eps"])
+    M, S = eps.shape[:2]
+    allp = orc.predict_all(X, mu, rho, eps)
+    for dtype, tol in (("fp32", 1e-5), ("bf16", 3e-2)):
+        res = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype=dtype, noise="injected", eps=eps.reshape(M * S, -1).to(d),
+                         return_samples=True)
+        assert np.max(np.abs(res.samples.cpu().numpy() - allp.numpy())) <= tol * max(1.0, float(allp.abs().max()))
+
+
+def test_single_sample_std_is_nan(golden):
+    from mcmc_amd import mc_predict
+    g = golden("predict_small.npz")
+    d = _dev()
+    X, mu, rho = (torch.from_numpy(g[k]).to(d) for k in ("X", "mu", "rho"))
+    res = mc_predict(X, mu[:1].contiguous(), rho[:1].contiguous(), 1, dtype="fp32", seed=1)
+    assert torch.isnan(res.std).all()  # torch.std of one sample (bayesian_ensemble.py:246)
+    assert torch.isfinite(res.mean).all()
+
+
+def test_reduce_kernel_bit_exact_vs_oracle():
+    from mcmc_amd.engine import Engine
+    d = _dev()
+    eng = Engine(d)
+    rng = np.random.default_rng(3)
+    for (C, B, nbins) in [(37, 70, 64), (256, 200, 128), (100, 65, 256), (64, 1, 512)]:
+        Y = (rng.normal(size=(C, B)) * rng.uniform(0.05, 3.0, size=B) + rng.normal(size=B) * 2).astype(np.float32)
+        Y[0, 0] = np.float32(1e6)   # overflow bin
+        Y[1, 0] = np.float32(-1e6)  # underflow bin
+        ldY = (B + 63) // 64 * 64
+        Yd = torch.zeros(C, ldY, device=d)
+        Yd[:, :B] = torch.from_numpy(Y).to(d)
+        pilot = eng.new_state(B)
+        npil = min(C, 16)
+        eng.reduce_update(Yd, ldY, npil, B, pilot)
+        st = eng.new_state(B, nbins)
+        eng.set_edges(B, npil, pilot.sum, pilot.sumsq, st, 6.0)
+        # two chunks: state carries over
+        eng.reduce_update(Yd, ldY, C // 2, B, st)
+        eng.reduce_update(Yd[C // 2:], ldY, C - C // 2, B, st)
+        s1 = Y[:npil].astype(np.float64).sum(0)
+        s2 = (Y[:npil].astype(np.float64) ** 2).sum(0)
+        lo, inv_w = orc.hist_edges_from_pilot(npil, s1, s2, nbins, 6.0)
+        assert np.array_equal(st.lo.cpu().numpy(), lo) and np.array_equal(st.inv_w.cpu().numpy(), inv_w)
+        hist = orc.hist_accumulate(Y, lo, inv_w, nbins)
+        got = st.hist.cpu().numpy().view(np.uint16).astype(np.int64)
+        assert np.array_equal(got, hist)
+        assert np.allclose(st.sum.cpu().numpy(), Y.astype(np.float64).sum(0), rtol=1e-13, atol=1e-9)
+        mean, std, quant = eng.finalize(B, st, Q)
+        m_ref, s_ref, q_ref = orc.finalize_from_state(C, Y.astype(np.float64).sum(0), (Y.astype(np.float64) ** 2).sum(0), hist, lo, inv_w, Q)
+        assert np.allclose(mean.cpu().numpy(), m_ref, rtol=1e-6, atol=1e-6)
+        assert np.allclose(std.cpu().numpy(), s_ref, rtol=1e-6)
+        assert np.allclose(quant.cpu().numpy(), q_ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N", [1, 2, 13, 32, 4096])
+def test_loss_forward_backward(golden, N):
+    from mcmc_amd import peak_weighted_loss
+    g = golden("loss.npz")
+    d = _dev()
+    p = torch.from_numpy(g[f"p_{N}"]).to(d).requires_grad_(True)
+    t = torch.from_numpy(g[f"t_{N}"]).to(d)
+    L = peak_weighted_loss(p, t)
+    L.backward()
+    L64, g64 = float(g[f"loss64_{N}"]), g[f"grad64_{N}"]
+    assert abs(float(L) - L64) <= 2e-6 * max(1.0, abs(L64))
+    assert np.max(np.abs(p.grad.cpu().numpy() - g64)) <= 2e-6 * max(1e-3, np.max(np.abs(g64)))
+    # and against the reference's own fp32 result
+    assert abs(float(L) - float(g[f"loss_{N}"])) <= 1e-5 * max(1.0, abs(L64))
+
+
+def test_loss_alpha_beta_and_large(golden):
+    from mcmc_amd import peak_weighted_loss
+    g = golden("loss.npz")
+    d = _dev()
+    p = torch.from_numpy(g["p_ab"]).to(d).requires_grad_(True)
+    t = torch.from_numpy(g["t_ab"]).to(d)
+    L = peak_weighted_loss(p, t, alpha=3.5, beta=1.0)
+    (2.0 * L).backward()
+    assert abs(float(L) - float(g["loss_ab"])) <= 1e-5
+    assert np.max(np.abs(p.grad.cpu().numpy() - 2.0 * g["grad_ab"])) <= 1e-6
+    # large N (config 5 shape per GPU: 4.56e6): closed form in fp64 on the host
+    rng = np.random.default_rng(0)
+    n = 4_560_001
+    tt = rng.normal(size=n).astype(np.float32)
+    pp = (tt + 0.3 * rng.normal(size=n)).astype(np.float32)
+    pt = torch.from_numpy(pp).to(d).requires_grad_(True)
+    Lb = peak_weighted_loss(pt, torch.from_numpy(tt).to(d))
+    Lb.backward()
+    L64, g64 = orc.peak_weighted_loss_closed_form(pp, tt)
+    assert abs(float(Lb) - L64) <= 1e-5 * L64
+    assert np.max(np.abs(pt.grad.cpu().numpy() - g64)) <= 1e-5 * np.max(np.abs(g64))
+
+
+def test_ensemble_class_contract(golden):
+    """Drop-in boundary: named ('batch',) fp32 tensors on the ensemble's device."""
+    from mcmc_amd import BayesianNetwork, GPUBayesianEnsemble
+    g = golden("predict_cfg1.npz")
+    d = _dev()
+    ens = GPUBayesianEnsemble(input_dim=11, device=d, batch_size=32, seed=7)
+    torch.manual_seed(0)
+    ens.models = [BayesianNetwork(11).to(d) for _ in range(5)]
+    X = torch.from_numpy(g["X"]).to(d).refine_names("time", "features")
+    mean, std = ens.predict(X)
+    assert mean.names == ("batch",) and std.names == ("batch",)
+    assert mean.dtype == torch.float32 and mean.shape == (365,) and mean.device.type == "cuda"
+    m2, s2 = ens(X)
+    assert m2.shape == (365,)
+    with pytest.raises(ValueError):
+        ens.predict(X.rename(None)[:, :7])
+    # statistical agreement with the oracle's own MC estimate (different noise: 500 samples)
+    mu, rho = orc.pack_members(ens.models)
+    m_ref, s_ref = orc.predict_reference_semantics(torch.from_numpy(g["X"]), mu, rho, 100)
+    se = s_ref.numpy() / np.sqrt(500)
+    assert np.mean(np.abs(mean.cpu().rename(None).numpy() - m_ref.numpy()) < 6 * se + 1e-4) > 0.99
+    mean, std, lo, hi = ens.predict_interval(X, 100)
+    assert torch.all(lo.rename(None) <= hi.rename(None))
+    # main.py:174-177 consumer idiom
+    _ = mean.cpu().rename(None).reshape(-1, 1)
+    _ = std.cpu().rename(None) * 2.0
