@@ -192,6 +192,24 @@ class Engine:
         return mean, std, quant
 
 
+class _timed:
+    """Bracket a launch with events on the current (= launch) stream."""
+
+    def __init__(self, timers: Optional[dict], name: str, units: int = 0):
+        self.timers, self.name, self.units = timers, name, units
+
+    def __enter__(self):
+        if self.timers is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+
+    def __exit__(self, *exc):
+        if self.timers is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            self.timers.setdefault(self.name, []).append((self.t0, t1, self.units))
+
+
 @dataclass
 class PredictResult:
     mean: torch.Tensor
@@ -217,7 +235,8 @@ def default_chunk_pairs(ldY: int, wpack_bytes: int, M: int, device) -> int:
 def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples: int, *, dtype="fp32",
                noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
                q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
-               chunk_pairs: Optional[int] = None, group=None, return_samples: bool = False) -> PredictResult:
+               chunk_pairs: Optional[int] = None, group=None, return_samples: bool = False,
+               timers: Optional[dict] = None) -> PredictResult:
     """Monte Carlo predictive statistics of the ensemble over X.
 
     X [B,F] fp32 on a HIP device; mu, rho [M,P] fp32 (pack_members).  noise: 'philox'
@@ -225,7 +244,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     size), 'injected' (eps [M*S,P] fp32 in the reference's draw order) or 'none' (sample=False).
     With torch.distributed initialised (backend 'nccl' = RCCL), the M*S pairs are sharded over
     the ranks of ``group`` and the partial (sum, sumsq, histogram) are combined by all-reduce;
-    every rank returns the full result.
+    every rank returns the full result.  ``timers``: optional dict; per kernel name it collects
+    (start, end) torch.cuda.Event pairs recorded on the launch stream around each launch.
     """
     import torch.distributed as dist
     dev_index = _require_gpu(X, "X")
@@ -275,8 +295,10 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
         first = True
         for begin in range(q_begin, q_end, Cn):
             cnt = min(Cn, q_end - begin)
-            eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
-            eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY)
+            with _timed(timers, "sample_weights"):
+                eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
+            with _timed(timers, "forward", cnt):
+                eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY)
             if nq and first:
                 # pilot: the first chunk's moments (all ranks') place every row's histogram
                 pilot = eng.new_state(B)
@@ -284,7 +306,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                 pilot = combine_partials(pilot, group)
                 eng.set_edges(B, pilot.n, pilot.sum, pilot.sumsq, st, range_sigmas)
             first = False
-            eng.reduce_update(Y, ldY, cnt, B, st)
+            with _timed(timers, "reduce_update", cnt):
+                eng.reduce_update(Y, ldY, cnt, B, st)
             if samples is not None:
                 samples[pair_global_ids(begin, cnt, M, S, eng.device)] = Y[:cnt, :B]
         if nq and first:  # a rank without pairs still joins the pilot combine
