@@ -14,6 +14,8 @@
 //     phi(a) = max(a, log2e * 2^min(a,0) - log2e) = log2e * elu(z)
 // = v_exp_f32 (clamp) + v_fma_f32 + v_max_f32 per element, the budget that keeps the VALU under
 // the MFMA time at 2 waves per SIMD.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mcmc {
@@ -25,10 +27,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kWaves = 8;
-constexpr int kMaxK0Steps = 2;  // input_dim + 1 <= 32
+constexpr int kDefaultWaves = 8;  // waves per workgroup (= per CU: the weight image allows one workgroup per CU)
 
 __device__ __forceinline__ float phi(float a) {
+#if defined(MCMC_ABLATE) && MCMC_ABLATE == 1  // tools/fwd_ablate.hip: no activation at all
+    return a;
+#elif defined(MCMC_ABLATE) && MCMC_ABLATE == 2  // no transcendental
+    float o;
+    const float e = fmaf(a, kLog2e, -kLog2e);
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(e));
+    return o;
+#elif defined(MCMC_ABLATE) && MCMC_ABLATE == 3  // transcendental only
+    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a), 0.0f, 1.0f);
+#else
     // 2^min(a,0): the clamp folds into v_exp_f32's output modifier
     const float t = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a), 0.0f, 1.0f);
     const float e = fmaf(t, kLog2e, -kLog2e);
@@ -36,6 +47,7 @@ __device__ __forceinline__ float phi(float a) {
     float o;
     asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(e));
     return o;
+#endif
 }
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& acc, int s) {
@@ -45,13 +57,14 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& acc, int s) {
     return o;
 }
 
-__global__ __launch_bounds__(64 * kWaves, 2) void forward_bf16_kernel(const unsigned short* __restrict__ xpack,
+template <int KS0, int kWaves>
+__global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(const unsigned short* __restrict__ xpack,
                                                                       int64_t n_rows, int F, int rows_per_block,
                                                                       const unsigned char* __restrict__ wpack,
                                                                       float* __restrict__ Y, int64_t ldY) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const WPackBF16 L(F);
-    const int ks0 = L.K0 / 16;
+    constexpr int ks0 = KS0;
     const int c = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -81,10 +94,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void forward_bf16_kernel(const unsi
         // the weight image is loop-invariant: without this the compiler hoists all 88 A
         // fragments (352 VGPRs) out of the tile loop and spills
         asm volatile("" ::: "memory");
-        bf16x8 xb[kMaxK0Steps];
+        bf16x8 xb[KS0];
 #pragma unroll
-        for (int s = 0; s < kMaxK0Steps; ++s)
-            if (s < ks0) xb[s] = *reinterpret_cast<const bf16x8*>(xpack + row * L.K0 + 16 * s + 8 * h);
+        for (int s = 0; s < KS0; ++s)
+            xb[s] = *reinterpret_cast<const bf16x8*>(xpack + row * L.K0 + 16 * s + 8 * h);
 
         // ---- layer 0: input_dim(+1) -> 256 ----
         bf16x8 hb1[16];
@@ -92,8 +105,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void forward_bf16_kernel(const unsi
         for (int mo = 0; mo < 8; ++mo) {
             f32x16 acc = {0};
 #pragma unroll
-            for (int s = 0; s < kMaxK0Steps; ++s)
-                if (s < ks0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[(mo * ks0 + s) * 64], xb[s], acc, 0, 0, 0);
+            for (int s = 0; s < KS0; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[(mo * ks0 + s) * 64], xb[s], acc, 0, 0, 0);
             hb1[2 * mo] = pack8(acc, 0);
             hb1[2 * mo + 1] = pack8(acc, 1);
         }
@@ -127,30 +140,50 @@ __global__ __launch_bounds__(64 * kWaves, 2) void forward_bf16_kernel(const unsi
     }
 }
 
+template <int KS0, int kWaves>
+static int launch_variant(const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count, float* Y, int64_t ldY,
+                          hipStream_t s) {
+    const WPackBF16 L(F);
+    const size_t lds_bytes = (size_t)L.total;
+    auto kern = forward_bf16_kernel<KS0, kWaves>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_bf16, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+    // Row superblock: large enough that staging 89 KB of weights is ~1 % of its MFMA time
+    // (64 tiles per wave at 8 waves), small enough that pairs x superblocks >> 256 CUs.
+    const int64_t padded = rows_pad(n_rows);
+    const int step = 32 * kWaves;
+    int rows_per_block = 16384 / step * step;
+    if (padded < rows_per_block) rows_per_block = (int)((padded + step - 1) / step * step);
+    const int64_t row_blocks = (padded + rows_per_block - 1) / rows_per_block;
+    for (int done = 0; done < pair_count;) {
+        const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
+        hipLaunchKernelGGL(kern, dim3((unsigned)row_blocks, n), dim3(64 * kWaves), lds_bytes, s, (const unsigned short*)xpack, n_rows,
+                           F, rows_per_block, (const unsigned char*)wpack + (int64_t)done * L.total, Y + (int64_t)done * ldY, ldY);
+        done += n;
+    }
+    return check_launch("forward_bf16");
+}
+
 }  // namespace
 
 int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
                         float* Y, int64_t ldY, hipStream_t s) {
-    const WPackBF16 L(F);
-    const size_t lds_bytes = (size_t)L.total;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(forward_bf16_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_bf16, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
-    // Row superblock: large enough that staging 89 KB of weights is ~1 % of its MFMA time
-    // (64 tiles per wave), small enough that pairs x superblocks >> 256 CUs.
-    const int64_t padded = rows_pad(n_rows);
-    int rows_per_block = 32 * kWaves * 64;
-    if (padded < rows_per_block) rows_per_block = (int)((padded + 32 * kWaves - 1) / (32 * kWaves) * (32 * kWaves));
-    const int64_t row_blocks = (padded + rows_per_block - 1) / rows_per_block;
-    for (int done = 0; done < pair_count;) {
-        const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
-        hipLaunchKernelGGL(forward_bf16_kernel, dim3((unsigned)row_blocks, n), dim3(64 * kWaves), lds_bytes, s,
-                           (const unsigned short*)xpack, n_rows, F, rows_per_block,
-                           (const unsigned char*)wpack + (int64_t)done * L.total, Y + (int64_t)done * ldY, ldY);
-        done += n;
-    }
     (void)ctx;
-    return check_launch("forward_bf16");
+    static const int waves = [] {
+        const char* e = getenv("MCMC_FWD_WAVES");  // tuning knob; default chosen by measurement
+        const int w = e ? atoi(e) : kDefaultWaves;
+        return (w == 8 || w == 12 || w == 16) ? w : kDefaultWaves;
+    }();
+    const bool one = WPackBF16(F).K0 == 16;
+#define MCMC_GO(KS, W) return launch_variant<KS, W>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s)
+    if (one) {
+        if (waves == 16) MCMC_GO(1, 16);
+        if (waves == 12) MCMC_GO(1, 12);
+        MCMC_GO(1, 8);
+    }
+    if (waves == 12) MCMC_GO(2, 12);  // 160 VGPRs: 16 waves do not fit
+    MCMC_GO(2, 8);
+#undef MCMC_GO
 }
 
 }  // namespace mcmc

@@ -1,0 +1,72 @@
+// Dev tool: time forward_bf16_kernel variants (MCMC_ABLATE=0..3, waves) without torch.
+//   hipcc -O3 --offload-arch=gfx950 -DMCMC_ABLATE=1 -Iinclude -Imcmc_amd/csrc tools/fwd_ablate.hip -o build/fwd_ablate1
+#include "../mcmc_amd/csrc/forward_bf16.hip"
+
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+namespace mcmc {
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+    return code;
+}
+}  // namespace mcmc
+
+#define CK(x)                                                                   \
+    do {                                                                        \
+        hipError_t e_ = (x);                                                    \
+        if (e_ != hipSuccess) {                                                 \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));             \
+            return 1;                                                           \
+        }                                                                       \
+    } while (0)
+
+int main(int argc, char** argv) {
+    const int64_t rows = argc > 1 ? atoll(argv[1]) : 365000;
+    const int pairs = argc > 2 ? atoi(argv[2]) : 1024;
+    const int iters = argc > 3 ? atoi(argv[3]) : 5;
+    const int F = 11;
+    const mcmc::WPackBF16 L(F);
+    const int64_t padded = mcmc::rows_pad(rows), ldY = (rows + 63) / 64 * 64;
+    // random bf16 in roughly [-0.25, 0.25] for weights, [-2, 2] for inputs
+    std::vector<unsigned short> hx(padded * L.K0), hw((size_t)pairs * L.total / 2);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    auto bf = [](float f) { union { float f; unsigned u; } c; c.f = f; const unsigned u = c.u; return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); };
+    for (auto& v : hx) v = bf(4.0f * rnd());
+    for (auto& v : hw) v = bf(0.5f * rnd());
+    void *dx, *dw;
+    float* dy;
+    CK(hipMalloc(&dx, hx.size() * 2));
+    CK(hipMalloc(&dw, hw.size() * 2));
+    CK(hipMalloc(&dy, (size_t)pairs * ldY * 4));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, dy, ldY, 0)) return 1;
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a, 0));
+        if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, dy, ldY, 0)) return 1;
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    const double units = (double)rows * pairs;
+#ifndef MCMC_ABLATE
+#define MCMC_ABLATE 0
+#endif
+    printf("ablate=%d waves=%s rows=%lld pairs=%d best %.3f ms  %.1f TFLOP/s(alg)\n", MCMC_ABLATE, getenv("MCMC_FWD_WAVES") ? getenv("MCMC_FWD_WAVES") : "default",
+           (long long)rows, pairs, best, units * 87680.0 / best / 1e9);
+    return 0;
+}
