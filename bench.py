@@ -69,12 +69,14 @@ def cpu_baseline(n_series: int, members: int, samples: int, seed: int):
                       f"best of 2, torch-CPU restatement of the reference predict() ({best:.2f} s)"}
 
 
-def load_traffic():
-    """HBM bytes per forward launch from the committed PMC passes (profiles/), or None."""
+def load_traffic(units_per_launch: float):
+    """HBM bytes per forward launch: bytes/unit from the committed PMC passes (profiles/
+    pmc_forward_bf16.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes) x this run's units per
+    launch, or None when the file is absent."""
     path = os.path.join(ROOT, "profiles", "pmc_forward_bf16.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            return json.load(f)["hbm_bytes_per_unit"] * units_per_launch
     except Exception:
         return None
 
@@ -164,7 +166,8 @@ def main():
                                    f"input_dim {X.shape[1]}, Philox weight noise, mean+std+95% interval ({args.nbins}-bin histogram)",
                        "units_per_step": units_per_step, "pairs_sharded_over": world},
             "roofline": {"bound": "mfma", "kernel": "forward_bf16_kernel", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE, "traffic": load_traffic(),
+                         "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE,
+                         "traffic": load_traffic(fwd_units / max(len(fwd_ms), 1)),
                          "launches": len(fwd_ms), "avg_launch_ms": (sum(fwd_ms) / len(fwd_ms)) if fwd_ms else None,
                          "flop_per_unit": FLOP_PER_UNIT},
             "reduce": {"bound": "hbm", "kernel": "reduce_update_kernel",

@@ -117,8 +117,10 @@ int mcmc_reduce_set_edges(mcmc_ctx* ctx, int64_t n_rows, int64_t n0, const doubl
                           float* inv_w, mcmc_stream_t stream);
 
 /* mean = sum/n, std = unbiased (n-1) like torch.std (bayesian_ensemble.py:245-246; NaN at n=1),
- * quant[k, row] = histogram quantile at q_levels[k] (host fp64 array, n_q <= 8; position q*(n-1)
- * like torch.quantile 'linear', interpolated inside the bin).  hist may be NULL iff n_q == 0. */
+ * quant[k, row] = histogram quantile at q_levels[k] (host fp64 array, n_q <= 8): torch.quantile's
+ * 'linear' rule - interpolate order statistics floor(q*(n-1)) and +1 - with each order statistic
+ * placed inside its own bin, so the result is within one bin width of the exact quantile.
+ * hist may be NULL iff n_q == 0. */
 int mcmc_reduce_finalize(mcmc_ctx* ctx, int64_t n_rows, int64_t n, const double* sum,
                          const double* sumsq, const uint16_t* hist, const float* lo,
                          const float* inv_w, int nbins, const double* q_levels, int n_q,

@@ -27,7 +27,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kDefaultWaves = 8;  // waves per workgroup (= per CU: the weight image allows one workgroup per CU)
+// Waves per workgroup (= per CU: the 89 KB weight image admits one workgroup per CU).  Measured on
+// MI355X (365k rows x 1024 pairs): 8 waves 917, 12 waves 963, 16 waves 973 TFLOP/s - the kernel is
+// VALU-issue-bound (ELU), more resident waves only close the scheduling gaps.
+constexpr int kDefaultWaves = 16;
 
 __device__ __forceinline__ float phi(float a) {
 #if defined(MCMC_ABLATE) && MCMC_ABLATE == 1  // tools/fwd_ablate.hip: no activation at all
@@ -65,7 +68,9 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const WPackBF16 L(F);
     constexpr int ks0 = KS0;
-    const int c = blockIdx.y;
+    // pair on blockIdx.x: the workgroups resident at one time share a row superblock, so its X
+    // tile (512 KB) is an L2 hit for all but the first of them
+    const int c = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
     const float b3 = *reinterpret_cast<const float*>(lds + L.b3);
 
     const int64_t padded = rows_pad(n_rows);
-    const int64_t blk_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t blk_begin = (int64_t)blockIdx.y * rows_per_block;
     int64_t blk_end = blk_begin + rows_per_block;
     if (blk_end > padded) blk_end = padded;
 
@@ -155,9 +160,10 @@ static int launch_variant(const void* xpack, int64_t n_rows, int F, const void* 
     int rows_per_block = 16384 / step * step;
     if (padded < rows_per_block) rows_per_block = (int)((padded + step - 1) / step * step);
     const int64_t row_blocks = (padded + rows_per_block - 1) / rows_per_block;
+    if (row_blocks > 65535) return set_error(MCMC_EINVAL, "n_rows too large for one launch (%lld row blocks)", (long long)row_blocks);
     for (int done = 0; done < pair_count;) {
         const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
-        hipLaunchKernelGGL(kern, dim3((unsigned)row_blocks, n), dim3(64 * kWaves), lds_bytes, s, (const unsigned short*)xpack, n_rows,
+        hipLaunchKernelGGL(kern, dim3(n, (unsigned)row_blocks), dim3(64 * kWaves), lds_bytes, s, (const unsigned short*)xpack, n_rows,
                            F, rows_per_block, (const unsigned char*)wpack + (int64_t)done * L.total, Y + (int64_t)done * ldY, ldY);
         done += n;
     }
@@ -172,7 +178,7 @@ int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, 
     static const int waves = [] {
         const char* e = getenv("MCMC_FWD_WAVES");  // tuning knob; default chosen by measurement
         const int w = e ? atoi(e) : kDefaultWaves;
-        return (w == 8 || w == 12 || w == 16) ? w : kDefaultWaves;
+        return (w == 8 || w == 12 || w == 16) ? w : kDefaultWaves;  // 16 falls back to 12 when input_dim > 14
     }();
     const bool one = WPackBF16(F).K0 == 16;
 #define MCMC_GO(KS, W) return launch_variant<KS, W>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s)
@@ -181,7 +187,7 @@ int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, 
         if (waves == 12) MCMC_GO(1, 12);
         MCMC_GO(1, 8);
     }
-    if (waves == 12) MCMC_GO(2, 12);  // 160 VGPRs: 16 waves do not fit
+    if (waves >= 12) MCMC_GO(2, 12);  // two layer-0 k-steps need 160 VGPRs: 16 waves do not fit
     MCMC_GO(2, 8);
 #undef MCMC_GO
 }

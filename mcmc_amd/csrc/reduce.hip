@@ -177,25 +177,31 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n_rows, double n,
         const uint32_t excl = incl - tot;
         const double lo = (double)lo_g[row];
         const double width = 1.0 / (double)inv_w_g[row];
-        for (int qi = 0; qi < ql.n; ++qi) {
-            const double pos = ql.q[qi] * (n - 1.0);
-            // first bin whose inclusive cumulative count exceeds pos
+        // estimate of the j-th order statistic (0-based): uniform spread inside its bin
+        auto order_stat = [&](double j) -> double {
             int kk = -1;
 #pragma unroll
             for (int k = K - 1; k >= 0; --k)
-                if ((double)(excl + cum[k]) > pos) kk = k;
+                if ((double)(excl + cum[k]) > j) kk = k;
             const unsigned long long ball = __ballot(kk >= 0);
             const int first = ball ? __ffsll((long long)ball) - 1 : 63;
-            if (lane == first) {
-                if (kk < 0) kk = K - 1;  // pos beyond all counts (cannot happen when hist sums to n)
-                const int b = lane * K + kk;
-                const double prev = (double)(excl + (kk > 0 ? cum[kk - 1] : 0u));
-                const double cb = (double)(cnt[kk] > 0 ? cnt[kk] : 1u);
-                double val = lo + ((double)(b - 1) + (pos + 0.5 - prev) / cb) * width;
-                if (b == 0) val = lo;
-                if (b == nbins - 1) val = lo + (double)(nbins - 2) * width;
-                quant[(int64_t)qi * n_rows + row] = (float)val;
-            }
+            if (kk < 0) kk = K - 1;  // j beyond all counts (cannot happen when hist sums to n)
+            const int b = lane * K + kk;
+            const double prev = (double)(excl + (kk > 0 ? cum[kk - 1] : 0u));
+            const double cb = (double)(cnt[kk] > 0 ? cnt[kk] : 1u);
+            double val = lo + ((double)(b - 1) + (j + 0.5 - prev) / cb) * width;
+            if (b == 0) val = lo;
+            if (b == nbins - 1) val = lo + (double)(nbins - 2) * width;
+            return __shfl(val, first);
+        };
+        for (int qi = 0; qi < ql.n; ++qi) {
+            // torch.quantile 'linear': position q*(n-1) between order statistics k and k+1
+            const double pos = ql.q[qi] * (n - 1.0);
+            const double k0 = floor(pos);
+            const double frac = pos - k0;
+            double val = order_stat(k0);
+            if (frac > 0.0 && k0 + 1.0 < n) val += frac * (order_stat(k0 + 1.0) - val);
+            if (lane == 0) quant[(int64_t)qi * n_rows + row] = (float)val;
         }
     }
 }

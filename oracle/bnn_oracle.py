@@ -316,10 +316,12 @@ def finalize_from_state(n: int, s1: np.ndarray, s2: np.ndarray, hist: Optional[n
                         q_levels: Sequence[float]):
     """(n, sum, sumsq, hist) -> mean, unbiased std, histogram quantiles.
 
-    Quantile rule (restates reduce.hip:finalize_kernel): target position pos = q*(n-1)
-    (torch.quantile's 'linear' position); find the bin b with cum[b-1] <= pos < cum[b];
-    value = edge_lo(b) + (pos + 0.5 - cum[b-1]) / hist[b] * width; under-/overflow bins
-    return the range edge."""
+    Quantile rule (restates reduce.hip:finalize_kernel): torch.quantile's 'linear' rule
+    interpolates order statistics k = floor(q*(n-1)) and k+1; each order statistic j is
+    estimated inside its own bin b (cum[b-1] <= j < cum[b]) as
+    edge_lo(b) + (j + 0.5 - cum[b-1]) / hist[b] * width, so every estimate - and their
+    interpolation - is within one bin width of the exact value; under-/overflow bins return
+    the range edge."""
     mean = s1 / n
     if n > 1:
         var = np.maximum((s2 - s1 * s1 / n) / (n - 1), 0.0)
@@ -333,15 +335,21 @@ def finalize_from_state(n: int, s1: np.ndarray, s2: np.ndarray, hist: Optional[n
         qs = np.empty((len(q_levels), B), dtype=np.float64)
         width = 1.0 / inv_w.astype(np.float64)
         lo64 = lo.astype(np.float64)
-        for qi, q in enumerate(q_levels):
-            pos = q * (n - 1)
-            b = (cum <= pos).sum(axis=1)  # first bin with cum > pos
+        def order_stat(j):
+            b = (cum <= j).sum(axis=1)  # first bin with cum > j
             b = np.minimum(b, nbins - 1)
             prev = np.where(b > 0, np.take_along_axis(cum, np.maximum(b - 1, 0)[:, None], axis=1)[:, 0], 0)
             cnt = np.take_along_axis(hist, b[:, None], axis=1)[:, 0]
-            frac = (pos + 0.5 - prev) / np.maximum(cnt, 1)
-            val = lo64 + ((b - 1) + frac) * width
+            val = lo64 + ((b - 1) + (j + 0.5 - prev) / np.maximum(cnt, 1)) * width
             val = np.where(b == 0, lo64, val)
-            val = np.where(b == nbins - 1, lo64 + (nbins - 2) * width, val)
+            return np.where(b == nbins - 1, lo64 + (nbins - 2) * width, val)
+
+        for qi, q in enumerate(q_levels):
+            pos = q * (n - 1)
+            k0 = math.floor(pos)
+            frac = pos - k0
+            val = order_stat(float(k0))
+            if frac > 0.0 and k0 + 1 < n:
+                val = val + frac * (order_stat(float(k0 + 1)) - val)
             qs[qi] = val
     return mean, std, qs

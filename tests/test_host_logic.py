@@ -1,0 +1,232 @@
+"""CPU-only tests: C-ABI surface, host-side mirror of the reference interface, pair sharding,
+the world_size-2 combine (gloo), and the batched generator.  No device compute is called."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnn_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# --------------------------------------------------------------------------- C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mcmc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mcmc_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 17
+    assert sorted(_lib.SIGNATURES) == declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_layout_queries_without_gpu():
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import param_count
+    lib = _lib.load()
+    assert lib.mcmc_abi_version() == _lib.ABI_VERSION
+    for F in (1, 7, 9, 11, 15, 16, 24):
+        assert lib.mcmc_param_count(F) == param_count(F) == orc.n_params(F)
+        assert lib.mcmc_wpack_bytes(F, _lib.DT_BF16) % 256 == 0
+        assert lib.mcmc_wpack_bytes(F, _lib.DT_F32) % 256 == 0
+    assert lib.mcmc_wpack_bytes(11, _lib.DT_BF16) == 91392
+    assert lib.mcmc_xpack_bytes(365, 11, _lib.DT_BF16) == 384 * 16 * 2
+    assert lib.mcmc_xpack_bytes(365, 11, _lib.DT_F32) == 384 * 12 * 4
+    # errors: negative code + message, no exception across the boundary
+    assert lib.mcmc_param_count(0) == -1
+    assert lib.mcmc_wpack_bytes(25, _lib.DT_BF16) == -1
+    assert b"input_dim" in lib.mcmc_last_error()
+    assert lib.mcmc_wpack_bytes(11, 7) == -1
+    with pytest.raises(ValueError):
+        _lib.check(lib.mcmc_xpack_bytes(-1, 11, 0), "mcmc_xpack_bytes")
+
+
+def test_context_needs_a_gpu():
+    from mcmc_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises((_lib.MCMCError, ValueError)):
+        _lib.Context(0)
+
+
+# --------------------------------------------------------------------------- mirror of the reference interface
+def test_ensemble_constructor_and_errors_match_reference():
+    from mcmc_amd import BayesianLinear, BayesianNetwork, GPUBayesianEnsemble
+    ens = GPUBayesianEnsemble(input_dim=11, device=torch.device("cpu"), batch_size=32)
+    assert (ens.input_dim, ens.n_models, ens.batch_size, ens.models) == (11, 5, 32, [])
+    assert isinstance(ens, torch.nn.Module)
+    with pytest.raises(ValueError, match="Input dimension mismatch. Expected 11, got 7"):
+        ens.train(torch.zeros(20, 7), torch.zeros(20))  # bayesian_ensemble.py:115-118
+    net = BayesianNetwork(11)
+    assert sum(p.numel() for p in net.parameters()) == 88578
+    assert [tuple(l.weight_mu.shape) for l in net.hidden_layers] == [(256, 11), (128, 256), (64, 128)]
+    assert tuple(net.output_layer.weight_rho.shape) == (1, 64)
+    assert float(net.hidden_layers[0].weight_rho[0, 0]) == -3.0 and float(net.output_layer.bias_mu[0]) == 0.0
+    with pytest.raises(ValueError, match="Expected 11 input features, got 5"):
+        net(torch.zeros(3, 5))
+    with pytest.raises(ValueError, match="Expected 256 input features"):
+        BayesianLinear(256, 128)(torch.zeros(2, 3))
+    out = net.eval()(torch.zeros(4, 11), sample=False)
+    assert out.names == ("batch",) and out.shape == (4,)
+    # same init distribution as the reference: identical under the same seed
+    sys.path.insert(0, "/root/reference")
+    try:
+        from models.bayesian_ensemble import BayesianNetwork as RefNet  # only when the reference is mounted
+    except Exception:
+        RefNet = None
+    finally:
+        sys.path.remove("/root/reference")
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.") or k == "utils"]:
+            del sys.modules[k]
+    if RefNet is not None:
+        torch.manual_seed(3)
+        a = RefNet(11)
+        torch.manual_seed(3)
+        b = BayesianNetwork(11)
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.equal(pa, pb)
+
+
+def test_predict_has_no_cpu_path():
+    from mcmc_amd import BayesianNetwork, GPUBayesianEnsemble, mc_predict, peak_weighted_loss
+    ens = GPUBayesianEnsemble(input_dim=11, device=torch.device("cpu"))
+    ens.models = [BayesianNetwork(11)]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ens.predict(torch.zeros(5, 11))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mc_predict(torch.zeros(5, 11), torch.zeros(1, 44289), torch.zeros(1, 44289), 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        peak_weighted_loss(torch.zeros(4), torch.zeros(4))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ens.train(torch.zeros(20, 11), torch.zeros(20))
+    empty = GPUBayesianEnsemble(input_dim=11, device=torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="no trained members"):
+        empty.predict(torch.zeros(5, 11))
+
+
+def test_pack_members_layout_matches_oracle():
+    from mcmc_amd import BayesianNetwork, pack_members
+    torch.manual_seed(0)
+    nets = [BayesianNetwork(9) for _ in range(3)]
+    mu, rho = pack_members(nets, "cpu")
+    mu_o, rho_o = orc.pack_members(nets)
+    assert torch.equal(mu, mu_o) and torch.equal(rho, rho_o)
+    offs = orc.param_offsets(9)
+    wo, bo, k_in, k_out = offs[1]
+    assert torch.equal(mu[2, wo:wo + k_in * k_out].view(k_out, k_in), nets[2].hidden_layers[1].weight_mu.detach())
+    assert torch.equal(mu[2, bo:bo + k_out], nets[2].hidden_layers[1].bias_mu.detach())
+
+
+# --------------------------------------------------------------------------- pair sharding
+@pytest.mark.parametrize("n,world", [(500, 1), (500, 2), (8192, 8), (7, 4), (3, 8)])
+def test_shard_pairs_partitions_exactly(n, world):
+    from mcmc_amd.engine import shard_pairs
+    cover = []
+    sizes = []
+    for r in range(world):
+        b, e = shard_pairs(n, r, world)
+        cover.extend(range(b, e))
+        sizes.append(e - b)
+    assert cover == list(range(n))
+    assert max(sizes) - min(sizes) <= 1
+
+
+def test_pair_order_is_a_member_interleaved_permutation():
+    from mcmc_amd.engine import pair_global_ids
+    M, S = 5, 100
+    g = pair_global_ids(0, M * S, M, S)
+    assert sorted(g.tolist()) == list(range(M * S))
+    # any chunk of consecutive q of length M holds every member once
+    assert sorted((g[35:40] // S).tolist()) == [0, 1, 2, 3, 4]
+    assert g[:6].tolist() == [0, 100, 200, 300, 400, 1]
+
+
+# --------------------------------------------------------------------------- world_size-2 combine over gloo
+def _combine_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mcmc_amd.engine import ReduceState, combine_partials, shard_pairs
+        rng = np.random.default_rng(0)
+        N, B, nbins = 64, 33, 128
+        Y = (rng.normal(size=(N, B)) * 1.5 + rng.normal(size=B)).astype(np.float32)  # all "samples", same on both ranks
+        b, e = shard_pairs(N, rank, world)
+        # pilot = each rank's first 8 samples, combined
+        pil = Y[b:b + 8].astype(np.float64)
+        pilot = ReduceState(8, torch.from_numpy(pil.sum(0)), torch.from_numpy((pil ** 2).sum(0)))
+        pilot = combine_partials(pilot)
+        assert pilot.n == 8 * world
+        lo, inv_w = orc.hist_edges_from_pilot(pilot.n, pilot.sum.numpy(), pilot.sumsq.numpy(), nbins, 6.0)
+        mine = Y[b:e]
+        hist = orc.hist_accumulate(mine, lo, inv_w, nbins).astype(np.uint16).view(np.int16)
+        st = ReduceState(e - b, torch.from_numpy(mine.astype(np.float64).sum(0)),
+                         torch.from_numpy((mine.astype(np.float64) ** 2).sum(0)), torch.from_numpy(hist.copy()),
+                         torch.from_numpy(lo), torch.from_numpy(inv_w), nbins)
+        st = combine_partials(st)
+        assert st.n == N
+        full_hist = orc.hist_accumulate(Y, lo, inv_w, nbins)
+        got_hist = st.hist.numpy().view(np.uint16).astype(np.int64)
+        assert np.array_equal(got_hist, full_hist)
+        mean, std, q = orc.finalize_from_state(st.n, st.sum.numpy(), st.sumsq.numpy(), got_hist, lo, inv_w, (0.025, 0.975))
+        tm, ts = orc.reduce_mean_std(torch.from_numpy(Y))
+        assert np.allclose(mean, tm.numpy(), atol=1e-6) and np.allclose(std, ts.numpy(), rtol=1e-5)
+        tq = torch.quantile(torch.from_numpy(Y), torch.tensor([0.025, 0.975]), dim=0).numpy()
+        assert np.all(np.abs(q - tq) <= 1.0 / inv_w[None, :])
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_combine_partials_world2_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_combine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_combine_is_identity_without_process_group():
+    from mcmc_amd.engine import ReduceState, combine_partials
+    st = ReduceState(3, torch.ones(4, dtype=torch.float64), torch.ones(4, dtype=torch.float64))
+    assert combine_partials(st) is st
+
+
+# --------------------------------------------------------------------------- generator (row f3)
+def test_series_batch_generator():
+    from mcmc_amd.data import calendar_features, make_series_batch
+    X, y = make_series_batch(50, seed=4, standardize=False)
+    assert X.shape == (50 * 365, 11) and y.shape == (50 * 365,)
+    Xs = X.view(50, 365, 11)
+    assert torch.all(Xs[:, :, 0].sum(1) == 24) and torch.all(Xs[:, :, 1].sum(1) == 30)  # data.py:57,74
+    assert torch.all(Xs[:, :, 2:5] == 0)                                                # data.py:127-129
+    assert torch.allclose(Xs[0, :, 5:], calendar_features())
+    assert float(y.min()) >= 0 and 900 < float(y.mean()) < 1400
+    X2, y2 = make_series_batch(50, seed=4, standardize=False)
+    assert torch.equal(X, X2) and torch.equal(y, y2)
+    X3, _ = make_series_batch(50, seed=5, standardize=False)
+    assert not torch.equal(X, X3)
+    Xn, yn = make_series_batch(50, seed=4)
+    assert torch.allclose(Xn.mean(0), torch.zeros(11), atol=1e-4)
+    assert torch.allclose(Xn.std(0, unbiased=False)[[0, 1, 5, 6, 7, 8, 9, 10]], torch.ones(8), atol=1e-3)
+    assert torch.all(Xn[:, 2:5] == 0)  # StandardScaler: zero-variance columns -> 0 (main.py:116-118)
+
+
+def test_calendar_features_match_reference_generator(golden):
+    """Same six sin/cos columns as data.py:155-167 (config-1 fixture's raw X, columns 5..10)."""
+    from mcmc_amd.data import calendar_features
+    g = golden("predict_cfg1.npz")
+    assert np.allclose(calendar_features().numpy(), g["X_raw"][:, 5:], atol=1e-6)
