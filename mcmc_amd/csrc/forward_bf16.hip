@@ -32,32 +32,39 @@ constexpr float kLog2e = 1.4426950408889634f;
 // VALU-issue-bound (ELU), more resident waves only close the scheduling gaps.
 constexpr int kDefaultWaves = 16;
 
-__device__ __forceinline__ float phi(float a) {
+// max(a, e) as one v_med3_f32 against FLT_MAX (saturating at FLT_MAX): a target intrinsic the
+// compiler cannot rewrite into maxnum, so it neither canonicalises the MFMA output first (plain
+// fmaxf costs a second v_max per element) nor pads an inline-asm boundary
+__device__ __forceinline__ float max_nc(float a, float e) { return __builtin_amdgcn_fmed3f(a, e, 3.402823466e+38f); }
+
+// phi over a 16-register accumulator tile, staged in groups of 8 (exps, then fmas, then maxes)
+// so no instruction waits on the one before it
+__device__ __forceinline__ void phi16(const f32x16& acc, float (&o)[16]) {
 #if defined(MCMC_ABLATE) && MCMC_ABLATE == 1  // tools/fwd_ablate.hip: no activation at all
-    return a;
-#elif defined(MCMC_ABLATE) && MCMC_ABLATE == 2  // no transcendental
-    float o;
-    const float e = fmaf(a, kLog2e, -kLog2e);
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(e));
-    return o;
-#elif defined(MCMC_ABLATE) && MCMC_ABLATE == 3  // transcendental only
-    return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a), 0.0f, 1.0f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = acc[i];
 #else
-    // 2^min(a,0): the clamp folds into v_exp_f32's output modifier
-    const float t = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a), 0.0f, 1.0f);
-    const float e = fmaf(t, kLog2e, -kLog2e);
-    // plain fmaxf makes hipcc canonicalise the MFMA output first (a second v_max per element)
-    float o;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(e));
-    return o;
+#pragma unroll
+    for (int g = 0; g < 16; g += 8) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(acc[g + i]), 0.0f, 1.0f);  // v_exp_f32 clamp
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = fmaf(t[i], kLog2e, -kLog2e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[g + i] = max_nc(acc[g + i], t[i]);
+    }
 #endif
 }
 
-__device__ __forceinline__ bf16x8 pack8(const f32x16& acc, int s) {
-    bf16x8 o;
+__device__ __forceinline__ void pack16(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
+    float o[16];
+    phi16(acc, o);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)phi(acc[8 * s + j]);
-    return o;
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = (__bf16)o[j];
+        hi[j] = (__bf16)o[8 + j];
+    }
 }
 
 template <int KS0, int kWaves>
@@ -112,8 +119,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
 #pragma unroll
             for (int s = 0; s < KS0; ++s)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[(mo * ks0 + s) * 64], xb[s], acc, 0, 0, 0);
-            hb1[2 * mo] = pack8(acc, 0);
-            hb1[2 * mo + 1] = pack8(acc, 1);
+            pack16(acc, hb1[2 * mo], hb1[2 * mo + 1]);
         }
         // ---- layer 1: 256 -> 128 ----
         bf16x8 hb2[8];
@@ -124,8 +130,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
             for (int i = 0; i < 16; ++i) acc[i] = B1[mo * 32 + i];
 #pragma unroll
             for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[(mo * 16 + s) * 64], hb1[s], acc, 0, 0, 0);
-            hb2[2 * mo] = pack8(acc, 0);
-            hb2[2 * mo + 1] = pack8(acc, 1);
+            pack16(acc, hb2[2 * mo], hb2[2 * mo + 1]);
         }
         // ---- layer 2: 128 -> 64, layer 3: 64 -> 1 on the VALU ----
         float y = 0.0f;
@@ -136,8 +141,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
             for (int i = 0; i < 16; ++i) acc[i] = B2[mo * 32 + i];
 #pragma unroll
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2[(mo * 8 + s) * 64], hb2[s], acc, 0, 0, 0);
+            float o[16];
+            phi16(acc, o);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) y = fmaf(W3[mo * 32 + i], phi(acc[i]), y);
+            for (int i = 0; i < 16; ++i) y = fmaf(W3[mo * 32 + i], o[i], y);
         }
         y += __shfl_xor(y, 32);
         y += b3;
