@@ -11,6 +11,10 @@
 //   packed uint16 pairs (row-rotated so rows falling in the same bin hit different banks), and
 //   are added to the global uint16 histogram once per chunk - the tile owns its rows, so global
 //   state is updated without atomics and the result is bitwise deterministic.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace mcmc {
@@ -103,6 +107,124 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update_kernel(const fl
             const int rl = i / words, w = i & (words - 1);
             if (row_base + rl < n_rows) {
                 const uint32_t add = lh[rl * words + ((w + rl) & (words - 1))];
+                if (add) hist[(row_base + rl) * words + w] += add;
+            }
+        }
+    }
+}
+
+// 16-byte variant (used whenever Y is 16-B aligned and ldY % 4 == 0): workgroup = 64 rows x 4
+// waves like above, but a lane owns 4 adjacent rows (one float4 load) and the 64 lanes of a wave
+// are 16 row-quads x 4 pairs, so each wave-load moves 4 x 256 B with a quarter of the load
+// instructions.  The histogram tile stays 64 rows (16 KB at 128 bins): 8 workgroups per CU.
+constexpr int kSlots = 4 * kWavesR;  // pairs in flight per workgroup step
+constexpr int kUnroll4 = 4;
+
+template <bool HIST>
+__global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const float* __restrict__ Y, int64_t ldY, int n_pairs,
+                                                                        int64_t n_rows, double* __restrict__ sum,
+                                                                        double* __restrict__ sumsq, const float* __restrict__ lo_g,
+                                                                        const float* __restrict__ inv_w_g,
+                                                                        uint32_t* __restrict__ hist, int nbins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* red = reinterpret_cast<double*>(smem);                                             // [2][kWavesR][kRows]
+    uint32_t* lh = reinterpret_cast<uint32_t*>(smem + 2 * kWavesR * kRows * sizeof(double));  // [kRows][nbins/2]
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rq = lane & 15, slot = wave * 4 + (lane >> 4);
+    const int64_t row_base = (int64_t)blockIdx.x * kRows;
+    const int64_t row0 = row_base + 4 * rq;
+    const bool loadable = row0 + 3 < ldY;  // the float4 stays inside the row pitch
+    const int words = nbins >> 1;
+
+    float lo[4] = {0, 0, 0, 0}, inv_w[4] = {0, 0, 0, 0};
+    if (HIST) {
+        for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) lh[i] = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (row0 + j < n_rows) {
+                lo[j] = lo_g[row0 + j];
+                inv_w[j] = inv_w_g[row0 + j];
+            }
+        __syncthreads();
+    }
+
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const f32x4* yp = reinterpret_cast<const f32x4*>(Y + row0);
+    const int64_t ld4 = ldY >> 2;
+    // Histogram address arithmetic, 9 VALU instructions per sample: with u = bin + 4*rq (the row
+    // quad rotates the word inside its row so the 16 quads of a lane group spread over the banks),
+    // word = (u >> 1) mod words, half = u & 1 = bin & 1.
+    const float hi_clamp = (float)(nbins - 2);
+    const int lw = 31 - __builtin_clz(words);
+    auto consume = [&](const f32x4& q, auto tail) {
+        const float v[4] = {q[0], q[1], q[2], q[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double d = (double)v[j];
+            s1[j] += d;
+            s2[j] = fma(d, d, s2[j]);
+            if (HIST && (!decltype(tail)::value || row0 + j < n_rows)) {
+                // same arithmetic as hist_bin(): two roundings, clamp to [-1, nbins-2] (NaN -> -1), floor
+                const float t = __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[j], lo[j]), inv_w[j]), -1.0f, hi_clamp);
+                int bm1;
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(bm1) : "v"(t));
+                const unsigned u = (unsigned)(bm1 + 1 + 4 * rq);
+                const unsigned word = __builtin_amdgcn_ubfe(u, 1, lw);
+                atomicAdd(&lh[(4 * rq + j) * words + word], (u & 1u) * 65535u + 1u);
+            }
+        }
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    const bool full_tile = row_base + kRows <= n_rows;  // block-uniform: no per-row bounds checks
+    int c = slot;
+    if (loadable) {
+        for (; c + (kUnroll4 - 1) * kSlots < n_pairs; c += kUnroll4 * kSlots) {
+            f32x4 q[kUnroll4];
+#pragma unroll
+            for (int u = 0; u < kUnroll4; ++u) q[u] = __builtin_nontemporal_load(yp + (int64_t)(c + u * kSlots) * ld4);
+            if (full_tile) {
+#pragma unroll
+                for (int u = 0; u < kUnroll4; ++u) consume(q[u], no{});
+            } else {
+#pragma unroll
+                for (int u = 0; u < kUnroll4; ++u) consume(q[u], yes{});
+            }
+        }
+        for (; c < n_pairs; c += kSlots) consume(__builtin_nontemporal_load(yp + (int64_t)c * ld4), yes{});
+    }
+    // the 4 pair-slots of a wave sit 16 lanes apart: fold them, then the waves through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s1[j] += __shfl_xor(s1[j], 16);
+        s1[j] += __shfl_xor(s1[j], 32);
+        s2[j] += __shfl_xor(s2[j], 16);
+        s2[j] += __shfl_xor(s2[j], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[wave * kRows + 4 * rq + j] = s1[j];
+            red[(kWavesR + wave) * kRows + 4 * rq + j] = s2[j];
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && row_base + lane < n_rows) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesR; ++w) {  // fixed order: deterministic
+            a += red[w * kRows + lane];
+            b += red[(kWavesR + w) * kRows + lane];
+        }
+        sum[row_base + lane] += a;
+        sumsq[row_base + lane] += b;
+    }
+    if (HIST) {
+        for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) {
+            const int rl = i / words, w = i & (words - 1);
+            if (row_base + rl < n_rows) {
+                const uint32_t add = lh[rl * words + ((w + 2 * (rl >> 2)) & (words - 1))];
                 if (add) hist[(row_base + rl) * words + w] += add;
             }
         }
@@ -211,10 +333,31 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n_rows, double n,
 int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
                          double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s) {
     (void)ctx;
+    static const bool force4b = getenv("MCMC_REDUCE_4B") != nullptr;  // dev knob: the 4-byte-per-lane kernel
+    const bool wide = !force4b && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0 && (ldY & 3) == 0;
+    if (wide) {
+        const int64_t blocks = (n_rows + kRows - 1) / kRows;
+        const size_t red_bytes = 2 * kWavesR * kRows * sizeof(double);
+        if (hist) {
+            const size_t lds = red_bytes + (size_t)kRows * (nbins / 2) * sizeof(uint32_t);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_update4_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(reduce_update4): %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(reduce_update4_kernel<true>, dim3((unsigned)blocks), dim3(kRows * kWavesR), lds, s, Y, ldY, n_pairs,
+                               n_rows, sum, sumsq, lo, inv_w, reinterpret_cast<uint32_t*>(hist), nbins);
+        } else {
+            hipLaunchKernelGGL(reduce_update4_kernel<false>, dim3((unsigned)blocks), dim3(kRows * kWavesR), red_bytes, s, Y, ldY,
+                               n_pairs, n_rows, sum, sumsq, nullptr, nullptr, nullptr, 0);
+        }
+        return check_launch("reduce_update");
+    }
     const int64_t blocks = (n_rows + kRows - 1) / kRows;
     const size_t red_bytes = 2 * kWavesR * kRows * sizeof(double);
     if (hist) {
         const size_t lds = red_bytes + (size_t)kRows * (nbins / 2) * sizeof(uint32_t);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_update_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(reduce_update): %s", hipGetErrorString(e));
         hipLaunchKernelGGL(reduce_update_kernel<true>, dim3((unsigned)blocks), dim3(kRows * kWavesR), lds, s, Y, ldY, n_pairs,
                            n_rows, sum, sumsq, lo, inv_w, reinterpret_cast<uint32_t*>(hist), nbins);
     } else {
