@@ -277,3 +277,104 @@ def test_ensemble_class_contract(golden):
     # main.py:174-177 consumer idiom
     _ = mean.cpu().rename(None).reshape(-1, 1)
     _ = std.cpu().rename(None) * 2.0
+
+
+def test_config3_full_size_properties():
+    """BASELINE configs[2] at full row count (10k series x 365 = 3.65 M rows, 8 members, bf16,
+    Philox) with a reduced sample count: size-independent properties + a row subsample against
+    the fp32 CPU restatement fed with the CPU restatement of the same Philox counters (2e-2)."""
+    from mcmc_amd import BayesianNetwork, mc_predict, pack_members
+    from mcmc_amd.data import make_series_batch
+    d = _dev()
+    M, S, seed = 8, 12, 424242
+    X, _ = make_series_batch(10_000, seed=2025, device=d)
+    assert X.shape == (3_650_000, 11)
+    torch.manual_seed(1)
+    nets = [BayesianNetwork(11) for _ in range(M)]
+    with torch.no_grad():
+        for n in nets:
+            for l in list(n.hidden_layers) + [n.output_layer]:
+                l.bias_mu.add_(0.1 * torch.randn_like(l.bias_mu))
+    mu, rho = pack_members(nets, d)
+    q = (0.025, 0.5, 0.975)
+    res = mc_predict(X, mu, rho, S, dtype="bf16", noise="philox", seed=seed, q_levels=q, nbins=128)
+    assert res.n_samples == M * S
+    assert torch.isfinite(res.mean).all() and torch.isfinite(res.std).all() and (res.std > 0).all()
+    # quantiles are sorted and bracket the mean's neighbourhood
+    assert (res.quantiles[0] <= res.quantiles[1]).all() and (res.quantiles[1] <= res.quantiles[2]).all()
+    # chunking (and hence launch shape) must not change the moments: fp64 sums of identical samples
+    res2 = mc_predict(X, mu, rho, S, dtype="bf16", noise="philox", seed=seed, q_levels=q, nbins=128, chunk_pairs=40)
+    assert torch.allclose(res2.mean, res.mean, rtol=0, atol=1e-6)
+    assert torch.allclose(res2.std, res.std, rtol=1e-6, atol=1e-7)
+    # identical rows (same calendar day, same indicators) give identical statistics
+    Xc = X.cpu()
+    same = (Xc[:365 * 50:365] == Xc[0]).all(dim=1).nonzero().flatten()
+    if len(same) > 1:
+        i, j = int(same[0]) * 365, int(same[1]) * 365
+        assert float(res.mean[i]) == float(res.mean[j]) and float(res.std[i]) == float(res.std[j])
+    # row subsample vs the oracle on the same noise
+    idx = torch.randperm(X.shape[0], generator=torch.Generator().manual_seed(0))[:48]
+    eps = torch.from_numpy(orc.philox_eps(seed, range(M * S), mu.shape[1])).reshape(M, S, -1)
+    allp = orc.predict_all(Xc[idx], mu.cpu(), rho.cpu(), eps)
+    m_ref, s_ref = orc.reduce_mean_std(allp)
+    scale = torch.maximum(m_ref.abs(), s_ref)
+    assert float(((res.mean.cpu()[idx] - m_ref).abs() / scale).max()) <= 2e-2
+    assert float(((res.std.cpu()[idx] - s_ref).abs() / s_ref).max()) <= 2e-2
+    tq = torch.quantile(allp, torch.tensor(q), dim=0)
+    width = res.bin_width.cpu()[idx]
+    assert ((res.quantiles.cpu()[:, idx] - tq).abs() <= width[None, :] + 2e-2 * scale[None, :]).all()
+
+
+def test_histogram_counts_sum_and_determinism(golden):
+    """Size-independent integer properties: every row's histogram sums to M*S; two runs with the
+    same key are bitwise identical (no atomics on global state)."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import Engine
+    g = golden("predict_cfg1.npz")
+    d = _dev()
+    eng = Engine(d)
+    X = torch.from_numpy(g["X"]).to(d)
+    mu, rho = torch.from_numpy(g["mu"]).to(d), torch.from_numpy(g["rho"]).to(d)
+    B, F = X.shape
+    M, S = mu.shape[0], 40
+    outs = []
+    for _ in range(2):
+        xp = eng.pack_x(X, _lib.DT_BF16)
+        wp = torch.empty(M * S * eng.wpack_bytes(F, _lib.DT_BF16), dtype=torch.uint8, device=d)
+        eng.sample_weights(mu, rho, S, F, 0, M * S, _lib.NOISE_PHILOX, None, 5, _lib.DT_BF16, wp)
+        ldY = 384
+        Y = torch.zeros(M * S, ldY, device=d)
+        eng.forward(_lib.DT_BF16, xp, B, F, wp, M * S, Y, ldY)
+        pilot = eng.new_state(B)
+        eng.reduce_update(Y, ldY, 20, B, pilot)
+        st = eng.new_state(B, 256)
+        eng.set_edges(B, 20, pilot.sum, pilot.sumsq, st, 6.0)
+        eng.reduce_update(Y, ldY, M * S, B, st)
+        counts = st.hist.cpu().numpy().view(np.uint16).astype(np.int64)
+        assert (counts.sum(1) == M * S).all()
+        outs.append((Y.cpu(), st.sum.cpu(), st.sumsq.cpu(), counts))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+
+
+def test_c_abi_rejects_bad_arguments():
+    """Error behaviour at the boundary: negative code + message -> ValueError, nothing launched."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import Engine, _p, _stream
+    d = _dev()
+    eng = Engine(d)
+    Y = torch.zeros(4, 64, device=d)
+    s = torch.zeros(64, dtype=torch.float64, device=d)
+    with pytest.raises(ValueError, match="nbins"):
+        _lib.check(eng.lib.mcmc_reduce_update(eng.ctx.handle, _p(Y), 64, 4, 64, _p(s), _p(s), _p(Y), _p(Y), _p(Y), 100, _stream()), "x")
+    with pytest.raises(ValueError, match="ldY"):
+        _lib.check(eng.lib.mcmc_forward(eng.ctx.handle, 0, _p(Y), 100, 11, _p(Y), 1, None, None, None, 1.0, _p(Y), 50, _stream()), "x")
+    with pytest.raises(ValueError, match="input_dim"):
+        _lib.check(eng.lib.mcmc_pack_x(eng.ctx.handle, _p(Y), 4, 99, 0, _p(Y), _stream()), "x")
+    with pytest.raises(ValueError, match="pair range"):
+        _lib.check(eng.lib.mcmc_sample_weights(eng.ctx.handle, _p(Y), _p(Y), 2, 3, 11, 4, 5, 2, None, 0, 0, _p(Y), _stream()), "x")
+    with pytest.raises(ValueError, match="65,535"):
+        _lib.check(eng.lib.mcmc_reduce_finalize(eng.ctx.handle, 64, 70000, _p(s), _p(s), _p(Y), _p(Y), _p(Y), 128,
+                                                (__import__("ctypes").c_double * 1)(0.5), 1, _p(Y), _p(Y), _p(Y), _stream()), "x")
+    # empty inputs are accepted and do nothing
+    assert eng.lib.mcmc_forward(eng.ctx.handle, 0, None, 0, 11, None, 0, None, None, None, 1.0, None, 0, _stream()) == 0
