@@ -142,6 +142,50 @@ int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n,
                        const double* stats, const double* part, float alpha, float beta,
                        float grad_scale, float* grad, mcmc_stream_t stream);
 
+/* ---- next row: one training step of all members --------------------------- */
+/* Replaces the inner loop of GPUBayesianEnsemble.train (bayesian_ensemble.py:160-181) for all
+ * n_members at once (the reference trains them one after the other, :135).  Pairs are indexed
+ * pair = member*n_samples + sample.  All buffers are caller-owned device memory:
+ *   mu, rho, sigma : [M,P]    parameters and sigma = exp(rho) (mcmc_train_sigma refreshes it)
+ *   eps, W, WT, dW : [M*S,P]  noise, effective weights ([out][in] and [in][out] per layer), and
+ *                             the gradient w.r.t. the effective weights of every pair
+ *   xb [M,rows,F], yb [M,rows] : each member's mini-batch (DataLoader order differs per member)
+ *   Y [M*S,rows], delta [M,rows], loss [M]
+ * mask_mode: 0 none, 1 host uint8 keep-masks [M*S,rows,256/128/64], 2 Philox keyed
+ * (mask_seed; pair, row, element) with keep probability 1-p_drop (bayesian_ensemble.py:71,86). */
+int mcmc_train_sigma(mcmc_ctx* ctx, const float* rho, float* sigma, int64_t n, mcmc_stream_t stream);
+/* eps (injected copy or Philox), W = mu + eps*sigma in both layouts (bayesian_ensemble.py:43-44). */
+int mcmc_train_sample(mcmc_ctx* ctx, const float* mu, const float* sigma, int n_members,
+                      int n_samples, int input_dim, int noise_mode, const float* eps_in,
+                      uint64_t seed, float* eps, float* W, float* WT, mcmc_stream_t stream);
+/* Train-mode forward of every pair over its member's batch (bayesian_ensemble.py:169-171). */
+int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members,
+                       int n_samples, const float* WT, int mask_mode, const uint8_t* mask0,
+                       const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                       float p_drop, float* Y, mcmc_stream_t stream);
+/* pred_mean over samples, peak_weighted_loss per member, delta = dLoss/dY of one sample
+ * (bayesian_ensemble.py:173-176, utils.py:7-28). */
+int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples,
+                    int64_t rows, float alpha, float beta, float* delta, float* loss,
+                    mcmc_stream_t stream);
+/* Backward of every pair (recomputes its forward with the same masks): dW (loss.backward, :178). */
+int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim,
+                        int n_members, int n_samples, const float* W, const float* WT,
+                        int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
+                        const uint8_t* mask2, uint64_t mask_seed, float p_drop,
+                        const float* delta, float* dW, mcmc_stream_t stream);
+/* gmu = sum_s dW, grho = sum_s dW*eps*sigma; clip_grad_norm_(max_norm) per member (:179); AdamW
+ * with torch's update rule (:180) on members whose active flag is set (NULL = all); refreshes
+ * sigma.  step = 1-based step count for the bias corrections.  adam_m/adam_v: [M,2P] (mu then
+ * rho), norm_scratch: fp64 [M*mcmc_train_norm_blocks()], gnorm: optional [M] pre-clip norms. */
+int mcmc_train_norm_blocks(void);
+int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members,
+                      int n_samples, int input_dim, const float* eps, const float* dW, float* gmu,
+                      float* grho, float* adam_m, float* adam_v, double* norm_scratch,
+                      const uint8_t* active, float lr, float beta1, float beta2, float adam_eps,
+                      float weight_decay, float max_norm, int64_t step, float* gnorm,
+                      mcmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,10 +13,8 @@ from typing import Optional, Sequence, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.utils.data import DataLoader, TensorDataset
 
 from . import engine
-from .loss import peak_weighted_loss
 
 
 class BayesianLinear(nn.Module):
@@ -98,55 +96,31 @@ class GPUBayesianEnsemble(nn.Module):
         self._seed = seed
         self._calls = 0
 
-    # ------------------------------------------------------------------ train (row f1: torch ops + fused loss)
+    # ------------------------------------------------------------------ train (row f1)
     def train(self, X: torch.Tensor = True, y: torch.Tensor = None, epochs: int = 400, num_samples: int = 10):
-        """Train the ensemble (bayesian_ensemble.py:107-209): same optimiser, schedule, clipping and
-        early stopping.  The sampled forwards/backwards still run as torch ops (SURVEY.md 8 f1 is the
-        next row); the loss step runs on the fused HIP kernel when the batch is on a HIP device."""
+        """Train the ensemble (bayesian_ensemble.py:107-209): same initialisation, optimiser (AdamW
+        1e-3 / wd 0.01), OneCycleLR schedule, clip_grad_norm_(1.0), per-member shuffles and early
+        stopping (patience 25) - but all members advance together, one fused HIP step per batch
+        (mcmc_amd.train.EnsembleTrainer) instead of the reference's member-after-member torch graph.
+        Weight noise and dropout masks come from the keyed Philox streams."""
         if isinstance(X, bool) and y is None:  # nn.Module.train(mode) - the reference shadows it; keep both usable
             return super().train(X)
+        from .train import EnsembleTrainer, fit_ensemble
         X = X.cpu().refine_names("time", "features")
         y = y.cpu().refine_names("time")
         if X.size("features") != self.input_dim:
             raise ValueError(f"Input dimension mismatch. Expected {self.input_dim}, got {X.size('features')}")
-        dataset = TensorDataset(X.rename(None), y.rename(None))
         if torch.device(self.device).type != "cuda":
             raise RuntimeError(f"GPUBayesianEnsemble needs a HIP device, got {self.device}; there is no CPU path "
                                "(the reference requires a GPU too: main.py:225-226)")
-        loader = DataLoader(dataset, batch_size=self.batch_size, shuffle=True, pin_memory=True, num_workers=0)
-        loss_fn = peak_weighted_loss
         self.models = []
-        for i in range(self.n_models):
-            model = BayesianNetwork(self.input_dim).to(self.device)
-            optimizer = torch.optim.AdamW(model.parameters(), lr=0.001, weight_decay=0.01)
-            scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=0.01, epochs=epochs, steps_per_epoch=len(loader),
-                                                            pct_start=0.3, anneal_strategy="cos")
-            best_loss, patience, patience_counter = float("inf"), 25, 0
-            for epoch in range(epochs):
-                epoch_loss = 0
-                model.train()
-                for batch_X, batch_y in loader:
-                    batch_X = batch_X.to(self.device)
-                    batch_y = batch_y.to(self.device)
-                    optimizer.zero_grad()
-                    predictions = torch.stack([model(batch_X, sample=True).rename(None) for _ in range(num_samples)], dim=0)
-                    pred_mean = predictions.mean(0)
-                    loss = loss_fn(pred_mean, batch_y)
-                    loss.backward()
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
-                    optimizer.step()
-                    scheduler.step()
-                    epoch_loss += loss.item()
-                if epoch_loss < best_loss:
-                    best_loss, patience_counter = epoch_loss, 0
-                else:
-                    patience_counter += 1
-                if patience_counter >= patience:
-                    print(f"Model {i + 1}/{self.n_models}: Early stopping at epoch {epoch}")
-                    break
-                if (epoch + 1) % 20 == 0:
-                    print(f"Model {i + 1}/{self.n_models}, Epoch {epoch + 1}/{epochs}, Loss: {epoch_loss:.4f}")
-            self.models.append(model)
+        members = [BayesianNetwork(self.input_dim).to(self.device) for _ in range(self.n_models)]
+        mu, rho = engine.pack_members(members, torch.device(self.device))
+        trainer = EnsembleTrainer(mu, rho, self.input_dim, num_samples)
+        self.epochs_trained = fit_ensemble(trainer, X.rename(None), y.rename(None), epochs=epochs, batch_size=self.batch_size,
+                                           seed=self._next_seed())
+        trainer.unpack_into(members)
+        self.models = members
         print(f"Finished training {self.n_models} models")
 
     # ------------------------------------------------------------------ predict (the hot path)

@@ -34,7 +34,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 1; }
+int mcmc_abi_version(void) { return 2; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -217,6 +217,85 @@ int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n,
     if (n == 0) return MCMC_OK;
     MCMC_REQUIRE(grad && aligned16(grad), "grad is NULL or not 16-byte aligned");
     return launch_loss_backward(ctx, p, t, n, n_total, stats, part, alpha, beta, grad_scale, grad, (hipStream_t)stream);
+}
+
+// ---- training step (row f1) ----------------------------------------------------------------------
+static int check_train(int n_members, int n_samples, int input_dim, int64_t rows) {
+    if (int rc = check_dims(input_dim, DT_F32)) return rc;
+    MCMC_REQUIRE(n_members >= 1 && n_samples >= 1 && (int64_t)n_members * n_samples <= 65535,
+                 "need n_members, n_samples >= 1 and n_members*n_samples <= 65535");
+    MCMC_REQUIRE(rows >= 1, "rows must be >= 1");
+    return MCMC_OK;
+}
+
+static int check_masks(int mask_mode, const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, float p_drop) {
+    MCMC_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "mask_mode must be 0 (none), 1 (host) or 2 (philox)");
+    MCMC_REQUIRE(mask_mode != 1 || (m0 && m1 && m2), "mask_mode 1 needs mask0, mask1 and mask2");
+    MCMC_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "p_drop must be in [0, 1)");
+    return MCMC_OK;
+}
+
+int mcmc_train_sigma(mcmc_ctx* ctx, const float* rho, float* sigma, int64_t n, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return MCMC_OK;
+    MCMC_REQUIRE(rho && sigma, "rho / sigma is NULL");
+    return launch_train_sigma(rho, sigma, n, (hipStream_t)stream);
+}
+
+int mcmc_train_sample(mcmc_ctx* ctx, const float* mu, const float* sigma, int n_members, int n_samples, int input_dim,
+                      int noise_mode, const float* eps_in, uint64_t seed, float* eps, float* W, float* WT, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, 1)) return rc;
+    MCMC_REQUIRE(noise_mode >= MCMC_NOISE_NONE && noise_mode <= MCMC_NOISE_PHILOX, "bad noise_mode %d", noise_mode);
+    MCMC_REQUIRE(noise_mode != MCMC_NOISE_INJECTED || eps_in, "MCMC_NOISE_INJECTED needs eps_in");
+    MCMC_REQUIRE(mu && sigma && eps && W && WT, "NULL pointer");
+    return launch_train_sample(mu, sigma, n_members, n_samples, input_dim, noise_mode, eps_in, seed, eps, W, WT, (hipStream_t)stream);
+}
+
+int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* WT,
+                       int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                       float p_drop, float* Y, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
+    if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
+    MCMC_REQUIRE(xb && WT && Y, "NULL pointer");
+    return launch_train_forward(xb, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y,
+                                (hipStream_t)stream);
+}
+
+int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples, int64_t rows, float alpha,
+                    float beta, float* delta, float* loss, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, 1, rows)) return rc;
+    MCMC_REQUIRE(Y && yb && delta && loss, "NULL pointer");
+    return launch_train_loss(Y, yb, n_members, n_samples, rows, alpha, beta, delta, loss, (hipStream_t)stream);
+}
+
+int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
+                        const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
+                        uint64_t mask_seed, float p_drop, const float* delta, float* dW, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
+    if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
+    MCMC_REQUIRE(xb && W && WT && delta && dW, "NULL pointer");
+    return launch_train_backward(xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
+                                 delta, dW, (hipStream_t)stream);
+}
+
+int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }
+
+int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members, int n_samples, int input_dim,
+                      const float* eps, const float* dW, float* gmu, float* grho, float* adam_m, float* adam_v, double* norm_scratch,
+                      const uint8_t* active, float lr, float beta1, float beta2, float adam_eps, float weight_decay, float max_norm,
+                      int64_t step, float* gnorm, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, 1)) return rc;
+    MCMC_REQUIRE(mu && rho && sigma && eps && dW && gmu && grho && adam_m && adam_v && norm_scratch, "NULL pointer");
+    MCMC_REQUIRE(step >= 1, "step is 1-based");
+    MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
+    return launch_train_update(mu, rho, sigma, n_members, n_samples, input_dim, eps, dW, gmu, grho, adam_m, adam_v, norm_scratch, active,
+                               lr, beta1, beta2, adam_eps, weight_decay, max_norm, step, gnorm, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -66,4 +66,19 @@ int launch_loss_backward(const mcmc_ctx* ctx, const float* p, const float* t, in
                          const double* stats, const double* part, float alpha, float beta, float grad_scale,
                          float* grad, hipStream_t s);
 
+int launch_train_sigma(const float* rho, float* sigma, int64_t n, hipStream_t s);
+int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F, int noise_mode, const float* eps_in, uint64_t seed,
+                        float* eps, float* W, float* WT, hipStream_t s);
+int launch_train_forward(const float* xb, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
+                         const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s);
+int launch_train_loss(const float* Y, const float* yb, int M, int S, int64_t rows, float alpha, float beta, float* delta, float* loss,
+                      hipStream_t s);
+int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
+                          const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
+                          float* dW, hipStream_t s);
+int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F, const float* eps, const float* dW, float* gmu,
+                        float* grho, float* am, float* av, double* normsq_part, const uint8_t* active, float lr, float beta1,
+                        float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s);
+int train_grad_blocks();
+
 }  // namespace mcmc

@@ -1,0 +1,220 @@
+"""Host driver of the ensemble training step.
+
+Replaces the reference's sequential member loop and its per-batch torch graph
+(/root/reference/models/bayesian_ensemble.py:135-202) with six launches per step that advance
+ALL members at once:
+
+    train_sample -> train_forward -> train_loss -> train_backward -> train_update (grad + AdamW)
+
+All arithmetic is in libmcmc_hip.so (include/mcmc_hip.h, mcmc_train_*); torch owns the device
+buffers, the batch gather and - on the host, on a parameter-less dummy optimiser - the
+OneCycleLR schedule, so lr / beta1 per step are the numbers the reference's scheduler produces.
+There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX
+from .engine import HIDDEN, Engine, _p, _stream, param_count
+
+MASK_NONE, MASK_HOST, MASK_PHILOX = 0, 1, 2
+_GOLDEN = 0x9E3779B97F4A7C15
+_U64 = 0xFFFFFFFFFFFFFFFF
+
+
+class EnsembleTrainer:
+    """Device state of M members trained in lock-step: parameters, AdamW moments, work buffers.
+
+    ``step`` is one pass of bayesian_ensemble.py:165-181 for every member on its own mini-batch.
+    Pair index = member * num_samples + sample keys the Philox noise / mask streams."""
+
+    def __init__(self, mu: torch.Tensor, rho: torch.Tensor, input_dim: int, num_samples: int = 10, *, p_drop: float = 0.1,
+                 weight_decay: float = 0.01, beta2: float = 0.999, adam_eps: float = 1e-8, max_norm: float = 1.0,
+                 alpha: float = 2.0, beta: float = 0.5):
+        self.eng = Engine(mu.device)
+        dev = self.eng.device
+        self.M, self.P = mu.shape
+        if self.P != param_count(input_dim):
+            raise ValueError(f"mu has {self.P} parameters per member, input_dim {input_dim} needs {param_count(input_dim)}")
+        if rho.shape != mu.shape:
+            raise ValueError("mu and rho must have the same shape")
+        self.F, self.S = input_dim, num_samples
+        self.p_drop, self.weight_decay, self.beta2, self.adam_eps, self.max_norm = p_drop, weight_decay, beta2, adam_eps, max_norm
+        self.alpha, self.beta = alpha, beta
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.mu = mu.detach().to(**f32).contiguous().clone()
+        self.rho = rho.detach().to(**f32).contiguous().clone()
+        self.sigma = torch.empty_like(self.rho)
+        pairs = self.M * self.S
+        self.eps = torch.empty(pairs, self.P, **f32)
+        self.W = torch.empty(pairs, self.P, **f32)
+        self.WT = torch.empty(pairs, self.P, **f32)
+        self.dW = torch.empty(pairs, self.P, **f32)
+        self.gmu = torch.empty(self.M, self.P, **f32)
+        self.grho = torch.empty(self.M, self.P, **f32)
+        self.adam_m = torch.zeros(self.M, 2 * self.P, **f32)
+        self.adam_v = torch.zeros(self.M, 2 * self.P, **f32)
+        self.norm_scratch = torch.empty(self.M * self.eng.lib.mcmc_train_norm_blocks(), dtype=torch.float64, device=dev)
+        self.gnorm = torch.empty(self.M, **f32)
+        self.loss = torch.empty(self.M, **f32)
+        self.t = 0  # AdamW step count (shared: all members start together; frozen members never resume)
+        self._Y = self._delta = None
+        h = self.eng.ctx.handle
+        _lib.check(self.eng.lib.mcmc_train_sigma(h, _p(self.rho), _p(self.sigma), self.rho.numel(), _stream()), "mcmc_train_sigma")
+
+    def _work(self, rows: int):
+        if self._Y is None or self._Y.shape[1] != rows:
+            self._Y = torch.empty(self.M * self.S, rows, dtype=torch.float32, device=self.eng.device)
+            self._delta = torch.empty(self.M, rows, dtype=torch.float32, device=self.eng.device)
+        return self._Y, self._delta
+
+    def step(self, xb: torch.Tensor, yb: torch.Tensor, lr: float, beta1: float = 0.9, *, noise: str = "philox",
+             eps: Optional[torch.Tensor] = None, seed: int = 0, masks: Optional[Sequence[torch.Tensor]] = None,
+             mask_seed: Optional[int] = None, dropout: bool = True, active: Optional[torch.Tensor] = None,
+             update: bool = True) -> torch.Tensor:
+        """One optimisation step of every (active) member.
+
+        xb [M,rows,F], yb [M,rows] fp32 on the device.  noise: 'philox' (keyed by ``seed``),
+        'injected' (eps [M,S,P]) or 'none'.  Dropout: host uint8 keep-masks (3 tensors
+        [M*S,rows,256/128/64]) when ``masks`` is given, else Philox masks keyed by ``mask_seed``
+        (default: seed), or none with dropout=False.  ``active`` [M] uint8 on the device freezes
+        members whose flag is 0 (early-stopped; they must not be re-activated later, the AdamW step
+        count is shared).  Returns the per-member loss [M] (device tensor, no sync)."""
+        lib, h = self.eng.lib, self.eng.ctx.handle
+        M, S, F = self.M, self.S, self.F
+        if xb.dim() != 3 or xb.shape[0] != M or xb.shape[2] != F:
+            raise ValueError(f"xb must be [{M}, rows, {F}], got {tuple(xb.shape)}")
+        rows = xb.shape[1]
+        if tuple(yb.shape) != (M, rows):
+            raise ValueError(f"yb must be [{M}, {rows}], got {tuple(yb.shape)}")
+        if not (xb.is_cuda and yb.is_cuda):
+            raise RuntimeError("xb / yb must live on the HIP device; mcmc_amd has no CPU path")
+        xb = xb.to(torch.float32).contiguous()
+        yb = yb.to(torch.float32).contiguous()
+        noise_mode = {"philox": NOISE_PHILOX, "injected": NOISE_INJECTED, "none": NOISE_NONE}[noise]
+        if noise_mode == NOISE_INJECTED:
+            if eps is None or eps.numel() != M * S * self.P:
+                raise ValueError(f"noise='injected' needs eps [{M},{S},{self.P}]")
+            eps = eps.to(device=self.eng.device, dtype=torch.float32).contiguous()
+        m0 = m1 = m2 = None
+        if masks is not None:
+            mask_mode = MASK_HOST
+            m0, m1, m2 = (m.to(device=self.eng.device, dtype=torch.uint8).contiguous() for m in masks)
+            for m, w in zip((m0, m1, m2), HIDDEN):
+                if m.numel() != M * S * rows * w:
+                    raise ValueError(f"mask must be [{M * S},{rows},{w}], got {tuple(m.shape)}")
+        else:
+            mask_mode = MASK_PHILOX if dropout else MASK_NONE
+        mseed = (seed if mask_seed is None else mask_seed) & _U64
+        Y, delta = self._work(rows)
+        st = _stream()
+        _lib.check(lib.mcmc_train_sample(h, _p(self.mu), _p(self.sigma), M, S, F, noise_mode, _p(eps), seed & _U64, _p(self.eps),
+                                         _p(self.W), _p(self.WT), st), "mcmc_train_sample")
+        _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed, self.p_drop,
+                                          _p(Y), st), "mcmc_train_forward")
+        _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, self.alpha, self.beta, _p(delta), _p(self.loss), st),
+                   "mcmc_train_loss")
+        _lib.check(lib.mcmc_train_backward(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
+                                           self.p_drop, _p(delta), _p(self.dW), st), "mcmc_train_backward")
+        if update:
+            self.t += 1
+            _lib.check(lib.mcmc_train_update(h, _p(self.mu), _p(self.rho), _p(self.sigma), M, S, F, _p(self.eps), _p(self.dW),
+                                             _p(self.gmu), _p(self.grho), _p(self.adam_m), _p(self.adam_v), _p(self.norm_scratch),
+                                             _p(active), lr, beta1, self.beta2, self.adam_eps, self.weight_decay, self.max_norm,
+                                             self.t, _p(self.gnorm), st), "mcmc_train_update")
+        return self.loss
+
+    def predictions(self) -> torch.Tensor:
+        """Y [M*S, rows] of the last step's train-mode forwards."""
+        return self._Y
+
+    def unpack_into(self, models: Sequence[torch.nn.Module]):
+        """Copy (mu, rho) back into modules with the reference's attribute names."""
+        with torch.no_grad():
+            for m, net in enumerate(models):
+                off = 0
+                for l in list(net.hidden_layers) + [net.output_layer]:
+                    nw, nb = l.weight_mu.numel(), l.bias_mu.numel()
+                    l.weight_mu.copy_(self.mu[m, off:off + nw].view_as(l.weight_mu))
+                    l.weight_rho.copy_(self.rho[m, off:off + nw].view_as(l.weight_rho))
+                    off += nw
+                    l.bias_mu.copy_(self.mu[m, off:off + nb])
+                    l.bias_rho.copy_(self.rho[m, off:off + nb])
+                    off += nb
+
+
+def one_cycle_schedule(epochs: int, steps_per_epoch: int) -> Tuple[List[float], List[float]]:
+    """(lr, beta1) for every step of the reference's AdamW(lr=1e-3) + OneCycleLR(max_lr=0.01,
+    pct_start=0.3, cos) (bayesian_ensemble.py:137-150), produced by torch's scheduler itself on a
+    throw-away host parameter."""
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([dummy], lr=0.001, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.01, epochs=epochs, steps_per_epoch=steps_per_epoch, pct_start=0.3,
+                                                anneal_strategy="cos")
+    lrs, b1s = [], []
+    total = epochs * steps_per_epoch
+    for i in range(total):
+        g = opt.param_groups[0]
+        lrs.append(float(g["lr"]))
+        b1s.append(float(g["betas"][0]))
+        if i + 1 < total:
+            opt.step()
+            sched.step()
+    return lrs, b1s
+
+
+def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epochs: int = 400, batch_size: int = 32, *,
+                 seed: int = 0, patience: int = 25, log=print, generator: Optional[torch.Generator] = None):
+    """The reference's training loop (bayesian_ensemble.py:152-200) for all members at once.
+
+    Every member draws its own shuffle of the rows per epoch (the reference builds one shuffling
+    DataLoader and iterates it once per member and epoch, :122-128,160), the ragged last batch is kept
+    (drop_last=False), epoch losses are summed per member, and a member stops updating after
+    ``patience`` epochs without improvement (:185-193) while the others go on.
+    Returns the list of per-member epoch counts actually trained."""
+    dev = trainer.eng.device
+    M = trainer.M
+    X = X.rename(None).to(device=dev, dtype=torch.float32)
+    y = y.rename(None).to(device=dev, dtype=torch.float32)
+    N = X.shape[0]
+    bounds = [(b, min(b + batch_size, N)) for b in range(0, N, batch_size)]
+    lrs, b1s = one_cycle_schedule(epochs, len(bounds))
+    best = torch.full((M,), float("inf"), dtype=torch.float64)
+    bad = torch.zeros(M, dtype=torch.int64)
+    alive = torch.ones(M, dtype=torch.bool)
+    active = torch.ones(M, dtype=torch.uint8, device=dev)
+    trained = [0] * M
+    it = 0
+    for epoch in range(epochs):
+        # per-member permutation, drawn on the host generator like DataLoader's sampler
+        perm = torch.stack([torch.randperm(N, generator=generator) for _ in range(M)]).to(dev)
+        Xe = X[perm]                      # [M, N, F]
+        ye = y[perm]                      # [M, N]
+        epoch_loss = torch.zeros(M, dtype=torch.float64, device=dev)
+        for (b0, b1) in bounds:
+            loss = trainer.step(Xe[:, b0:b1], ye[:, b0:b1], lrs[it], b1s[it], seed=(seed + _GOLDEN * (it + 1)) & _U64, active=active)
+            epoch_loss += loss.double()
+            it += 1
+        el = epoch_loss.cpu()             # one sync per epoch
+        for m in range(M):
+            if not alive[m]:
+                continue
+            trained[m] = epoch + 1
+            if el[m] < best[m]:
+                best[m], bad[m] = el[m], 0
+            else:
+                bad[m] += 1
+            if bad[m] >= patience:
+                alive[m] = False
+                log(f"Model {m + 1}/{M}: Early stopping at epoch {epoch}")
+            elif (epoch + 1) % 20 == 0:
+                log(f"Model {m + 1}/{M}, Epoch {epoch + 1}/{epochs}, Loss: {float(el[m]):.4f}")
+        if not alive.any():
+            break
+        active = alive.to(torch.uint8).to(dev)
+    return trained

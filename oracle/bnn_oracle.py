@@ -277,6 +277,70 @@ def philox_eps(seed: int, pair_ids: Sequence[int], P: int) -> np.ndarray:
     return philox_normals(seed, pair, idx)
 
 
+
+def philox_keep_masks(seed: int, pair: int, rows: int, p_drop: float = P_DROP):
+    """Dropout keep-masks [rows,256],[rows,128],[rows,64] of one pair from the 'MASK' Philox stream.
+
+    Counter = (elem>>2, pair, 0x4D41534B ['MASK'], row), key = seed; component elem&3;
+    elem runs over the 448 hidden activations (256 | 128 | 64); keep iff u01 < 1-p (fp32 compare).
+    Same keying as mcmc_amd/csrc/philox.hpp:philox_mask_uniform / train.hip:keep_flag.
+    """
+    n_el = sum(HIDDEN)
+    row = np.arange(rows, dtype=np.uint32)[:, None]
+    elem = np.arange(n_el, dtype=np.uint32)[None, :]
+    row, elem = np.broadcast_arrays(row, elem)
+    ctr = np.stack([elem >> np.uint32(2), np.full_like(elem, pair), np.full_like(elem, 0x4D41534B), row], axis=-1)
+    key = np.stack([np.full_like(elem, seed & 0xFFFFFFFF), np.full_like(elem, (seed >> 32) & 0xFFFFFFFF)], axis=-1)
+    x = philox4x32_10(ctr, key)
+    u = _u01(np.take_along_axis(x, (elem & np.uint32(3)).astype(np.int64)[..., None], axis=-1)[..., 0])
+    keep = (u < np.float32(1.0 - p_drop)).astype(np.uint8)
+    a, b = HIDDEN[0], HIDDEN[0] + HIDDEN[1]
+    return keep[:, :a], keep[:, a:b], keep[:, b:]
+
+
+# --------------------------------------------------------------------------- training step (row f1)
+class TrainOracle:
+    """One member's optimisation state, stepped exactly like the reference's inner loop
+    (bayesian_ensemble.py:137-150 optimiser + schedule, :165-181 step): S train-mode forwards with
+    the given eps / dropout masks, mean over samples, peak_weighted_loss, backward,
+    clip_grad_norm_(1.0), torch's own AdamW.  Parameters are kept flat ([P] mu, [P] rho): the
+    global-norm clip and the element-wise AdamW do not depend on how parameters are grouped."""
+
+    def __init__(self, mu: torch.Tensor, rho: torch.Tensor, lr: float = 0.001, weight_decay: float = 0.01):
+        self.mu = torch.nn.Parameter(mu.detach().clone().float())
+        self.rho = torch.nn.Parameter(rho.detach().clone().float())
+        self.opt = torch.optim.AdamW([self.mu, self.rho], lr=lr, weight_decay=weight_decay)
+
+    def one_cycle(self, epochs: int, steps_per_epoch: int):
+        """The reference's schedule (bayesian_ensemble.py:143-150)."""
+        self.sched = torch.optim.lr_scheduler.OneCycleLR(self.opt, max_lr=0.01, epochs=epochs, steps_per_epoch=steps_per_epoch,
+                                                         pct_start=0.3, anneal_strategy="cos")
+        return self.sched
+
+    def step(self, xb: torch.Tensor, yb: torch.Tensor, eps: torch.Tensor, masks=None, lr: Optional[float] = None,
+             beta1: Optional[float] = None, max_norm: float = 1.0):
+        """eps [S,P]; masks: None or 3 tensors [S,rows,256/128/64].  Returns (loss, grad_mu, grad_rho,
+        total_norm) with the gradients as they were BEFORE clipping."""
+        g = self.opt.param_groups[0]
+        if lr is not None:
+            g["lr"] = lr
+        if beta1 is not None:
+            g["betas"] = (beta1, g["betas"][1])
+        self.opt.zero_grad()
+        preds = []
+        for s in range(eps.shape[0]):
+            mk = None if masks is None else [torch.as_tensor(m[s]) for m in masks]
+            preds.append(forward_pair(xb, self.mu, self.rho, eps[s], mk))
+        pred_mean = torch.stack(preds, dim=0).mean(0)
+        loss = peak_weighted_loss(pred_mean, yb)
+        loss.backward()
+        gmu, grho = self.mu.grad.detach().clone(), self.rho.grad.detach().clone()
+        total = torch.nn.utils.clip_grad_norm_([self.mu, self.rho], max_norm)
+        self.opt.step()
+        if getattr(self, "sched", None) is not None and lr is None:
+            self.sched.step()
+        return loss.detach(), gmu, grho, total.detach()
+
 # --------------------------------------------------------------------------- streaming stats + histogram
 def hist_edges_from_pilot(n0: int, s1: np.ndarray, s2: np.ndarray, nbins: int, range_sigmas: float):
     """Per-row histogram placement from pilot moments (fp64 in, fp32 lo / inv_w out).

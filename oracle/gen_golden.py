@@ -17,6 +17,9 @@ What is captured:
   train_fwd.npz       train-mode forward (noise + live dropout masks, captured by a forward
                       hook on model.dropout): eps, masks, outputs.
   loss.npz            peak_weighted_loss value + autograd grad at N in {1, 13, 32, 4096}.
+  train_steps.npz     the reference's own GPUBayesianEnsemble.train run on CPU (2 members, 2 epochs
+                      of a 32-row and a 13-row batch, 2 samples): initial (mu, rho), and per step the
+                      batch, eps, dropout masks, lr / beta1 the optimiser used, loss; final (mu, rho).
 """
 from __future__ import annotations
 
@@ -238,11 +241,90 @@ def gen_loss():
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **rec)
 
 
+def gen_train_steps():
+    """Run the reference's train() itself on CPU and record everything its RNG decided."""
+    import models.bayesian_ensemble as ref_mod  # reference
+    F_in, N, M, S, epochs = 7, 45, 2, 2, 2
+    torch.manual_seed(31)
+    X = torch.randn(N, F_in)
+    y = torch.randn(N) + (torch.rand(N) > 0.85).float() * 2.0
+    inits, xbs, ybs, losses, lrs, beta1s, masks = [], [], [], [], [], [], []
+
+    orig_init = ref_mod.BayesianNetwork.__init__
+    orig_fwd = ref_mod.BayesianNetwork.forward
+    orig_loss = ref_mod.peak_weighted_loss
+    orig_drop = torch.nn.Dropout.forward
+    orig_step = torch.optim.AdamW.step
+
+    def init_wrap(self, *a, **k):
+        orig_init(self, *a, **k)
+        inits.append(orc.pack_members([self]))
+
+    def fwd_wrap(self, x, sample=False):
+        xbs.append(x.rename(None).detach().clone())
+        return orig_fwd(self, x, sample)
+
+    def loss_wrap(p, t, *a, **k):
+        L = orig_loss(p, t, *a, **k)
+        ybs.append(t.detach().clone())
+        losses.append(L.detach().clone())
+        return L
+
+    def drop_wrap(self, x):
+        out = orig_drop(self, x)
+        keep = torch.where(x != 0, (out != 0), torch.ones_like(out, dtype=torch.bool))
+        masks.append(keep.to(torch.uint8).clone())
+        return out
+
+    def step_wrap(self, *a, **k):
+        lrs.append(float(self.param_groups[0]["lr"]))
+        beta1s.append(float(self.param_groups[0]["betas"][0]))
+        assert self.param_groups[0]["betas"][1] == 0.999 and self.param_groups[0]["eps"] == 1e-8
+        assert self.param_groups[0]["weight_decay"] == 0.01
+        return orig_step(self, *a, **k)
+
+    ens = GPUBayesianEnsemble(input_dim=F_in, n_models=M, device=torch.device("cpu"), batch_size=32)
+    ref_mod.BayesianNetwork.__init__ = init_wrap
+    ref_mod.BayesianNetwork.forward = fwd_wrap
+    ref_mod.peak_weighted_loss = loss_wrap
+    torch.nn.Dropout.forward = drop_wrap
+    torch.optim.AdamW.step = step_wrap
+    try:
+        torch.manual_seed(4242)
+        with EpsRecorder() as rec:
+            ens.train(X, y, epochs=epochs, num_samples=S)
+    finally:
+        ref_mod.BayesianNetwork.__init__ = orig_init
+        ref_mod.BayesianNetwork.forward = orig_fwd
+        ref_mod.peak_weighted_loss = orig_loss
+        torch.nn.Dropout.forward = orig_drop
+        torch.optim.AdamW.step = orig_step
+    P = orc.n_params(F_in)
+    n_steps = len(losses)               # M * epochs * 2 batches
+    assert n_steps == M * epochs * 2 and len(xbs) == n_steps * S and len(masks) == n_steps * S * 3
+    eps = torch.cat(rec.draws).reshape(n_steps, S, P)
+    out = dict(X=X.numpy(), y=y.numpy(), M=M, S=S, epochs=epochs, steps_per_member=n_steps // M,
+               lr=np.array(lrs), beta1=np.array(beta1s), loss=torch.stack(losses).numpy())
+    for m in range(M):
+        out[f"mu0_{m}"], out[f"rho0_{m}"] = (t.numpy()[0] for t in inits[m])
+        mu1, rho1 = orc.pack_members([ens.models[m]])
+        out[f"mu1_{m}"], out[f"rho1_{m}"] = mu1.numpy()[0], rho1.numpy()[0]
+    for i in range(n_steps):
+        out[f"xb_{i}"] = xbs[i * S].numpy()
+        assert all(torch.equal(xbs[i * S], xbs[i * S + s]) for s in range(S))
+        out[f"yb_{i}"] = ybs[i].numpy()
+        out[f"eps_{i}"] = eps[i].numpy()
+        for l in range(3):
+            out[f"mask{l}_{i}"] = torch.stack([masks[(i * S + s) * 3 + l] for s in range(S)]).numpy()
+    np.savez_compressed(os.path.join(OUT, "train_steps.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_predict_small()
     gen_predict_cfg1()
     gen_train_fwd()
     gen_loss()
+    gen_train_steps()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

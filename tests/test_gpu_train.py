@@ -1,0 +1,220 @@
+"""GPU parity of the training step against oracle.TrainOracle and against the
+trajectory the reference's own train() produced (tests/golden/train_steps.npz)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _members(F, M, seed):
+    g = torch.Generator().manual_seed(seed)
+    P = orc.n_params(F)
+    mu = torch.zeros(M, P)
+    rho = torch.full((M, P), -3.0)
+    for m in range(M):
+        for (wo, bo, k_in, k_out) in orc.param_offsets(F):
+            mu[m, wo:wo + k_in * k_out] = torch.randn(k_in * k_out, generator=g) * (2.0 / k_in) ** 0.5
+            mu[m, bo:bo + k_out] = 0.1 * torch.randn(k_out, generator=g)
+        rho[m] += 0.5 * torch.randn(P, generator=g)
+    return mu, rho
+
+
+def _batch(M, rows, F, seed):
+    g = torch.Generator().manual_seed(seed)
+    xb = torch.randn(M, rows, F, generator=g)
+    yb = torch.randn(M, rows, generator=g) + (torch.rand(M, rows, generator=g) > 0.85).float() * 2.0
+    return xb, yb
+
+
+def _masks(M, S, rows, seed, p=0.1):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.rand(M * S, rows, w, generator=g) >= p).to(torch.uint8) for w in orc.HIDDEN]
+
+
+def _assert_params_close(got, want, lr_sum, what):
+    """Adam's update lr*m/(sqrt(v)+eps) is sign-like: where |g| ~ adam_eps (1e-8) an fp32-rounding
+    difference in g moves the update by a sizeable part of lr.  Hence: a hard bound of the total
+    step budget on every element, and a tight bound on 99.9 % of them.  (The update kernel itself is
+    checked tightly below against torch.optim.AdamW fed with the device's own gradients.)"""
+    d = (got - want).abs()
+    assert float(d.max()) <= 2.0 * lr_sum + 1e-6, f"{what}: max diff {float(d.max()):.3e}"
+    assert float(torch.quantile(d.flatten()[:1_000_000], 0.999)) <= 2e-6, what
+
+
+class _ShadowAdamW:
+    """torch.optim.AdamW + clip_grad_norm_ on the host, fed with the DEVICE's gradients."""
+
+    def __init__(self, mu, rho):
+        self.p = [torch.nn.Parameter(torch.cat([mu[m], rho[m]]).clone()) for m in range(mu.shape[0])]
+        self.opt = [torch.optim.AdamW([q], lr=0.001, weight_decay=0.01) for q in self.p]
+
+    def step(self, gmu, grho, lr, beta1):
+        for m, (q, o) in enumerate(zip(self.p, self.opt)):
+            o.param_groups[0]["lr"] = lr
+            o.param_groups[0]["betas"] = (beta1, 0.999)
+            q.grad = torch.cat([gmu[m], grho[m]]).clone()
+            torch.nn.utils.clip_grad_norm_([q], 1.0)
+            o.step()
+
+
+@pytest.mark.parametrize("F,rows,S", [(11, 32, 3), (7, 13, 2), (11, 45, 2), (24, 1, 2)])
+def test_train_step_matches_oracle(F, rows, S):
+    from mcmc_amd.train import EnsembleTrainer
+    M = 2
+    mu, rho = _members(F, M, 5 + F)
+    tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    oracles = [orc.TrainOracle(mu[m], rho[m]) for m in range(M)]
+    shadow = _ShadowAdamW(mu, rho)
+    P = orc.n_params(F)
+    lrs, b1s = [4e-4, 8e-3, 2.8e-3], [0.95, 0.87, 0.92]
+    for it in range(3):
+        xb, yb = _batch(M, rows, F, 100 + it)
+        eps = torch.randn(M, S, P, generator=torch.Generator().manual_seed(200 + it))
+        masks = _masks(M, S, rows, 300 + it)
+        loss = tr.step(xb.to(DEV), yb.to(DEV), lrs[it], b1s[it], noise="injected", eps=eps, masks=masks).cpu()
+        gmu, grho, gnorm = tr.gmu.cpu(), tr.grho.cpu(), tr.gnorm.cpu()
+        shadow.step(gmu, grho, lrs[it], b1s[it])
+        for m in range(M):
+            got = torch.cat([tr.mu[m], tr.rho[m]]).cpu()
+            np.testing.assert_allclose(got.numpy(), shadow.p[m].detach().numpy(), rtol=1e-6, atol=1e-6, err_msg=f"AdamW kernel, step {it}")
+            mk = [mm.view(M, S, rows, -1)[m] for mm in masks]
+            L, omu, orho, total = oracles[m].step(xb[m], yb[m], eps[m], mk, lr=lrs[it], beta1=b1s[it])
+            if rows > 1:  # rows == 1: target std is NaN in the reference as well; loss still finite
+                np.testing.assert_allclose(loss[m].item(), L.item(), rtol=2e-5)
+            scale = float(omu.abs().max()) + 1e-12
+            assert float((gmu[m] - omu).abs().max()) <= 2e-5 * scale + 1e-7, (it, m)
+            assert float((grho[m] - orho).abs().max()) <= 2e-5 * max(float(orho.abs().max()), 1e-6) + 1e-7, (it, m)
+            np.testing.assert_allclose(gnorm[m].item(), total.item(), rtol=2e-5)
+            _assert_params_close(tr.mu[m].cpu(), oracles[m].mu.detach(), sum(lrs[:it + 1]), f"mu step {it} member {m}")
+            _assert_params_close(tr.rho[m].cpu(), oracles[m].rho.detach(), sum(lrs[:it + 1]), f"rho step {it} member {m}")
+        np.testing.assert_allclose(tr.sigma.cpu().numpy(), np.exp(tr.rho.cpu().numpy()), rtol=2e-6)
+
+
+def test_train_replays_reference_trajectory(golden):
+    """Both golden members stepped together with the eps / masks / lr / beta1 the reference used."""
+    from mcmc_amd.train import EnsembleTrainer
+    z = golden("train_steps.npz")
+    M, S, spm = int(z["M"]), int(z["S"]), int(z["steps_per_member"])
+    mu0 = torch.stack([torch.from_numpy(z[f"mu0_{m}"]) for m in range(M)])
+    rho0 = torch.stack([torch.from_numpy(z[f"rho0_{m}"]) for m in range(M)])
+    F = z["X"].shape[1]
+    tr = EnsembleTrainer(mu0.to(DEV), rho0.to(DEV), F, S)
+    for j in range(spm):
+        idx = [m * spm + j for m in range(M)]
+        assert all(z[f"xb_{i}"].shape == z[f"xb_{idx[0]}"].shape for i in idx)
+        assert all(z["lr"][i] == z["lr"][idx[0]] for i in idx)
+        xb = torch.stack([torch.from_numpy(z[f"xb_{i}"]) for i in idx]).to(DEV)
+        yb = torch.stack([torch.from_numpy(z[f"yb_{i}"]) for i in idx]).to(DEV)
+        eps = torch.stack([torch.from_numpy(z[f"eps_{i}"]) for i in idx])
+        masks = [torch.cat([torch.from_numpy(z[f"mask{l}_{i}"]) for i in idx]) for l in range(3)]
+        loss = tr.step(xb, yb, float(z["lr"][idx[0]]), float(z["beta1"][idx[0]]), noise="injected", eps=eps, masks=masks).cpu()
+        np.testing.assert_allclose(loss.numpy(), z["loss"][idx], rtol=3e-5)
+    lr_sum = float(z["lr"][:spm].sum())
+    for m in range(M):
+        _assert_params_close(tr.mu[m].cpu(), torch.from_numpy(z[f"mu1_{m}"]), lr_sum, f"final mu member {m}")
+        _assert_params_close(tr.rho[m].cpu(), torch.from_numpy(z[f"rho1_{m}"]), lr_sum, f"final rho member {m}")
+
+
+def test_train_philox_noise_and_masks_match_oracle_streams():
+    """Device Philox eps / keep-masks equal the oracle's restatement of the same keying."""
+    from mcmc_amd.train import EnsembleTrainer
+    F, M, S, rows = 9, 2, 2, 20
+    mu, rho = _members(F, M, 77)
+    tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    xb, yb = _batch(M, rows, F, 78)
+    seed, mseed = 0x1234567890ABCDEF, 987654321
+    tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, seed=seed, mask_seed=mseed, update=False)
+    P = orc.n_params(F)
+    eps_ref = orc.philox_eps(seed, list(range(M * S)), P)
+    np.testing.assert_allclose(tr.eps.cpu().numpy(), eps_ref, rtol=0, atol=3e-6)
+    Y = tr.predictions().cpu()
+    eps_dev = tr.eps.cpu()
+    for pair in range(M * S):
+        m = pair // S
+        mk = [torch.from_numpy(k) for k in orc.philox_keep_masks(mseed, pair, rows)]
+        want = orc.forward_pair(xb[m], mu[m], rho[m], eps_dev[pair], mk)
+        np.testing.assert_allclose(Y[pair].numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_train_inactive_member_is_frozen():
+    from mcmc_amd.train import EnsembleTrainer
+    F, M, S, rows = 11, 3, 2, 32
+    mu, rho = _members(F, M, 9)
+    tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    xb, yb = _batch(M, rows, F, 10)
+    active = torch.tensor([1, 0, 1], dtype=torch.uint8, device=DEV)
+    tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, seed=3, active=active)
+    assert torch.equal(tr.mu[1].cpu(), mu[1]) and torch.equal(tr.rho[1].cpu(), rho[1])
+    assert not torch.equal(tr.mu[0].cpu(), mu[0]) and not torch.equal(tr.mu[2].cpu(), mu[2])
+    assert float(tr.adam_v[1].abs().max()) == 0.0
+
+
+def test_fit_ensemble_learns_and_stops_early():
+    from mcmc_amd.train import EnsembleTrainer, fit_ensemble
+    from mcmc_amd.data import make_series_batch
+    F, M, S = 11, 3, 4
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(365, F, generator=g)
+    w = torch.randn(F, generator=g)
+    y = torch.tanh(X @ w) + 0.05 * torch.randn(365, generator=g)
+    mu, rho = _members(F, M, 21)
+    tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    logs = []
+    first = None
+    trained = fit_ensemble(tr, X, y, epochs=12, seed=5, log=logs.append, generator=torch.Generator().manual_seed(1))
+    assert trained == [12] * M
+    # evaluate: deterministic forward (no noise, no dropout) through the same train kernels
+    xb = X.to(DEV).expand(M, -1, -1).contiguous()
+    yb = y.to(DEV).expand(M, -1).contiguous()
+    tr0 = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    l0 = tr0.step(xb, yb, 0.0, 0.9, noise="none", dropout=False, update=False).cpu()
+    l1 = tr.step(xb, yb, 0.0, 0.9, noise="none", dropout=False, update=False).cpu()
+    assert (l1 < 0.5 * l0).all(), (l0, l1)
+    # patience 1 with an impossible-to-improve setting (lr schedule still moves; just exercise the path)
+    tr2 = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    trained2 = fit_ensemble(tr2, X, y, epochs=30, seed=5, patience=1, log=logs.append, generator=torch.Generator().manual_seed(1))
+    assert all(1 <= t <= 30 for t in trained2) and any("Early stopping" in s for s in logs)
+
+
+def test_train_capi_rejects_bad_arguments():
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import Engine
+    eng = Engine(torch.device(DEV))
+    lib, h = eng.lib, eng.ctx.handle
+    buf = torch.zeros(1 << 16, device=DEV)
+    p = C.c_void_p(buf.data_ptr())
+    z = C.c_void_p(0)
+    assert lib.mcmc_train_forward(h, p, 32, 11, 300, 300, p, 0, z, z, z, 0, 0.1, p, z) == -1      # too many pairs
+    assert lib.mcmc_train_forward(h, p, 32, 11, 1, 1, p, 1, z, z, z, 0, 0.1, p, z) == -1          # host masks missing
+    assert lib.mcmc_train_forward(h, p, 32, 11, 1, 1, p, 2, z, z, z, 0, 1.0, p, z) == -1          # p_drop == 1
+    assert lib.mcmc_train_forward(h, p, 0, 11, 1, 1, p, 0, z, z, z, 0, 0.1, p, z) == -1           # rows == 0
+    assert lib.mcmc_train_sample(h, p, p, 1, 1, 11, 1, z, 0, p, p, p, z) == -1                    # injected without eps
+    assert lib.mcmc_train_update(h, p, p, p, 1, 1, 11, p, p, p, p, p, p, p, z, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0, z, z) == -1
+    assert b"step" in lib.mcmc_last_error()
+
+
+def test_ensemble_train_then_predict_end_to_end():
+    """GPUBayesianEnsemble.train (fused HIP steps) -> predict, through the reference's API."""
+    from mcmc_amd import GPUBayesianEnsemble
+    g = torch.Generator().manual_seed(3)
+    F = 11
+    X = torch.randn(200, F, generator=g)
+    y = torch.sin(X[:, 0]) + 0.5 * X[:, 1] + 0.05 * torch.randn(200, generator=g)
+    torch.manual_seed(11)
+    ens = GPUBayesianEnsemble(input_dim=F, n_models=3, device=torch.device(DEV), seed=17)
+    ens.train(X, y, epochs=15, num_samples=4)
+    assert len(ens.models) == 3 and ens.epochs_trained == [15, 15, 15]
+    mean, std = ens.predict(X, num_samples=50)
+    assert mean.names == ("batch",) and std.names == ("batch",)
+    mse = float(((mean.rename(None).cpu() - y) ** 2).mean())
+    assert mse < 0.25 * float(y.var()), mse          # an untrained ensemble sits near var(y) or above
+    assert float(std.rename(None).min()) > 0
+    with pytest.raises(ValueError):
+        ens.train(X[:, :5], y, epochs=1)

@@ -120,3 +120,46 @@ def test_histogram_quantiles_within_one_bin():
     tm, ts = orc.reduce_mean_std(torch.from_numpy(Y))
     assert np.allclose(mean, tm.numpy(), rtol=1e-6, atol=1e-6)
     assert np.allclose(std, ts.numpy(), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- training step (row f1)
+def test_train_oracle_reproduces_reference_trajectory(golden):
+    """TrainOracle stepped with the eps / masks / lr / beta1 the reference's own train() used must
+    land on the reference's losses and final (mu, rho)."""
+    z = golden("train_steps.npz")
+    M, S, spm = int(z["M"]), int(z["S"]), int(z["steps_per_member"])
+    for m in range(M):
+        orc_m = orc.TrainOracle(torch.from_numpy(z[f"mu0_{m}"]), torch.from_numpy(z[f"rho0_{m}"]))
+        for j in range(spm):
+            i = m * spm + j
+            masks = [torch.from_numpy(z[f"mask{l}_{i}"]) for l in range(3)]
+            loss, _, _, _ = orc_m.step(torch.from_numpy(z[f"xb_{i}"]), torch.from_numpy(z[f"yb_{i}"]),
+                                       torch.from_numpy(z[f"eps_{i}"]), masks, lr=float(z["lr"][i]), beta1=float(z["beta1"][i]))
+            np.testing.assert_allclose(loss.numpy(), z["loss"][i], rtol=2e-6)
+        np.testing.assert_allclose(orc_m.mu.detach().numpy(), z[f"mu1_{m}"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(orc_m.rho.detach().numpy(), z[f"rho1_{m}"], rtol=0, atol=2e-6)
+
+
+def test_train_oracle_schedule_matches_reference(golden):
+    """The OneCycleLR the oracle builds yields the lr / beta1 sequence the reference's optimiser saw."""
+    z = golden("train_steps.npz")
+    spm, epochs = int(z["steps_per_member"]), int(z["epochs"])
+    o = orc.TrainOracle(torch.from_numpy(z["mu0_0"]), torch.from_numpy(z["rho0_0"]))
+    sched = o.one_cycle(epochs, spm // epochs)
+    for j in range(spm):
+        g = o.opt.param_groups[0]
+        assert abs(g["lr"] - z["lr"][j]) <= 1e-12 and abs(g["betas"][0] - z["beta1"][j]) <= 1e-12
+        o.opt.step()
+        if j + 1 < spm:
+            sched.step()
+
+
+def test_philox_keep_masks_rate_and_determinism():
+    a = orc.philox_keep_masks(99, 3, 64)
+    b = orc.philox_keep_masks(99, 3, 64)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert [x.shape for x in a] == [(64, 256), (64, 128), (64, 64)]
+    rate = np.concatenate([x.reshape(-1) for x in a]).mean()
+    assert abs(rate - 0.9) < 0.01
+    c = orc.philox_keep_masks(99, 4, 64)
+    assert not np.array_equal(a[0], c[0])
