@@ -17,6 +17,10 @@ What is captured:
   train_fwd.npz       train-mode forward (noise + live dropout masks, captured by a forward
                       hook on model.dropout): eps, masks, outputs.
   loss.npz            peak_weighted_loss value + autograd grad at N in {1, 13, 32, 4096}.
+  glue_cfg1.npz       main.py:71-130,174-177 run with the real sklearn StandardScaler and the reference's
+                      utils.evaluate_predictions on the config-1 series for several feature subsets
+                      (main.py itself needs prophet, absent here: its few lines are re-run verbatim in
+                      spirit by gen_glue below, on the reference's data.py output).
   train_steps.npz     the reference's own GPUBayesianEnsemble.train run on CPU (2 members, 2 epochs
                       of a 32-row and a 13-row batch, 2 samples): initial (mu, rho), and per step the
                       batch, eps, dropout masks, lr / beta1 the optimiser used, loss; final (mu, rho).
@@ -319,6 +323,37 @@ def gen_train_steps():
     np.savez_compressed(os.path.join(OUT, "train_steps.npz"), **out)
 
 
+def gen_glue():
+    from sklearn.preprocessing import StandardScaler
+    from itertools import combinations
+    from utils import evaluate_predictions as ref_eval  # reference
+    X_raw, y_raw, _, _, _, _ = make_cfg1_inputs(seed=2025)
+    features, temporal = X_raw[:, :5], X_raw[:, 5:]
+    combos = [tuple()]
+    for r in range(1, 6):
+        combos.extend(combinations(range(5), r))
+    out = dict(features=features.numpy(), temporal=temporal.numpy(), target=y_raw.numpy(), n_combos=len(combos),
+               combo_order=np.array(["_".join(map(str, c)) if c else "baseline" for c in combos]))
+    torch.manual_seed(77)
+    for tag, combo in (("baseline", ()), ("0", (0,)), ("1_3", (1, 3)), ("0_1_2_3_4", (0, 1, 2, 3, 4))):
+        f = features.index_select(1, torch.tensor(list(combo))) if combo else features
+        X = torch.cat([f, temporal], dim=1)
+        sx, sy = StandardScaler(), StandardScaler()
+        Xs = torch.tensor(sx.fit_transform(X.numpy()))
+        ys = torch.tensor(sy.fit_transform(y_raw.numpy().reshape(-1, 1))).squeeze(-1)
+        fake_mean = ys + 0.2 * torch.randn(ys.shape)   # stands in for the ensemble's scaled-space output
+        fake_std = 0.1 + 0.05 * torch.rand(ys.shape)
+        m = sy.inverse_transform(fake_mean.reshape(-1, 1)).flatten()
+        sd = fake_std * sy.scale_[0]
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            met = ref_eval(y_raw.numpy(), m)
+        out.update({f"Xs_{tag}": Xs.numpy(), f"ys_{tag}": ys.numpy(), f"fake_mean_{tag}": fake_mean.numpy(),
+                    f"fake_std_{tag}": fake_std.numpy(), f"mean_{tag}": np.asarray(m), f"std_{tag}": sd.numpy(),
+                    f"rmse_{tag}": met["rmse"], f"mape_{tag}": met["mape"]})
+    np.savez_compressed(os.path.join(OUT, "glue_cfg1.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_predict_small()
@@ -326,5 +361,6 @@ if __name__ == "__main__":
     gen_train_fwd()
     gen_loss()
     gen_train_steps()
+    gen_glue()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -218,3 +218,24 @@ def test_ensemble_train_then_predict_end_to_end():
     assert float(std.rename(None).min()) > 0
     with pytest.raises(ValueError):
         ens.train(X[:, :5], y, epochs=1)
+
+
+def test_pipeline_bayesian_task_end_to_end(golden, tmp_path):
+    """main.py's Bayesian leg on the config-1 series: select -> scale -> train -> predict -> de-scale -> JSON."""
+    import json
+    from mcmc_amd import pipeline
+    z = golden("glue_cfg1.npz")
+    feats, temp, target = (torch.from_numpy(z[k]) for k in ("features", "temporal", "target"))
+    torch.manual_seed(5)
+    res = pipeline.train_and_evaluate_all(feats.refine_names("time", "features"), temp.refine_names("time", "temporal_features"),
+                                          target.refine_names("time"), combos=[(), (0, 1)], devices=[torch.device(DEV)],
+                                          epochs=40, predict_samples=50, interval=0.95, seed=3, log=lambda *_: None)
+    assert set(res["predictions"]) == {"baseline", "0_1"} and len(res["actual"]) == 365
+    for name, rec in res["predictions"].items():
+        b = rec["bayesian"]
+        assert len(b["predictions"]) == len(b["uncertainty"]) == len(b["lower"]) == 365
+        assert b["metrics"]["mape"] < 12.0, (name, b["metrics"])      # target ~1000 +- 250: an untrained net is > 20 %
+        assert min(b["uncertainty"]) > 0
+        assert sum(lo <= hi for lo, hi in zip(b["lower"], b["upper"])) == 365
+    pipeline.save_results(res, str(tmp_path / "model_results.json"))
+    assert json.loads((tmp_path / "model_results.json").read_text())["predictions"]["0_1"]["bayesian"]["metrics"]["rmse"] > 0

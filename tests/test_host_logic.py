@@ -230,3 +230,61 @@ def test_calendar_features_match_reference_generator(golden):
     from mcmc_amd.data import calendar_features
     g = golden("predict_cfg1.npz")
     assert np.allclose(calendar_features().numpy(), g["X_raw"][:, 5:], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- main.py glue (row f2)
+GLUE_TAGS = {"baseline": (), "0": (0,), "1_3": (1, 3), "0_1_2_3_4": (0, 1, 2, 3, 4)}
+
+
+def test_pipeline_feature_combinations_match_reference_order(golden):
+    from mcmc_amd import pipeline
+    z = golden("glue_cfg1.npz")
+    combos = pipeline.prepare_feature_combinations(5)
+    assert len(combos) == int(z["n_combos"]) == 32
+    assert [pipeline.combo_name(c) for c in combos] == [str(s) for s in z["combo_order"]]
+
+
+@pytest.mark.parametrize("tag", sorted(GLUE_TAGS))
+def test_pipeline_scaling_matches_sklearn(golden, tag):
+    from mcmc_amd import pipeline
+    z = golden("glue_cfg1.npz")
+    X = pipeline.select_features(torch.from_numpy(z["features"]), torch.from_numpy(z["temporal"]), GLUE_TAGS[tag])
+    assert X.names == ("time", "features") and X.shape[1] == len(GLUE_TAGS[tag] or range(5)) + 6
+    Xs, ys, sx, sy = pipeline.scale_inputs(X, torch.from_numpy(z["target"]))
+    assert Xs.names == ("time", "features") and ys.names == ("time",) and Xs.dtype == torch.float32
+    # float32 results of float64 statistics: at most one float32 ulp from sklearn's
+    np.testing.assert_allclose(Xs.rename(None).numpy(), z[f"Xs_{tag}"], rtol=3e-7, atol=3e-7)
+    np.testing.assert_allclose(ys.rename(None).numpy(), z[f"ys_{tag}"], rtol=3e-7, atol=3e-7)
+    mean, std = pipeline.descale_prediction(torch.from_numpy(z[f"fake_mean_{tag}"]), torch.from_numpy(z[f"fake_std_{tag}"]), sy)
+    assert mean.dtype == torch.float64 and std.dtype == torch.float32
+    np.testing.assert_allclose(mean.numpy(), z[f"mean_{tag}"], rtol=1e-12)
+    np.testing.assert_allclose(std.numpy(), z[f"std_{tag}"], rtol=3e-7)
+    met = pipeline.evaluate_predictions(z["target"], z[f"mean_{tag}"])
+    assert abs(met["rmse"] - float(z[f"rmse_{tag}"])) <= 1e-6 * float(z[f"rmse_{tag}"])
+    assert abs(met["mape"] - float(z[f"mape_{tag}"])) <= 1e-6 * float(z[f"mape_{tag}"])
+
+
+def test_pipeline_record_schema_and_constant_columns(golden, tmp_path):
+    import json
+    from mcmc_amd import pipeline
+    z = golden("glue_cfg1.npz")
+    X = pipeline.select_features(torch.from_numpy(z["features"]), torch.from_numpy(z["temporal"]), ())
+    Xs, ys, sx, sy = pipeline.scale_inputs(X, torch.from_numpy(z["target"]))
+    # the three placeholder indicator columns are constant zero (data.py:127-129): they stay 0, not NaN
+    assert torch.equal(Xs.rename(None)[:, 2:5], torch.zeros(365, 3))
+    y = torch.from_numpy(z["target"])
+    rec = pipeline.bayesian_record(ys.rename(None), torch.full((365,), 0.1), y, sy, ys.rename(None) - 0.2, ys.rename(None) + 0.2)
+    assert set(rec) == {"predictions", "uncertainty", "metrics", "lower", "upper"} and set(rec["metrics"]) == {"rmse", "mape"}
+    assert len(rec["predictions"]) == len(rec["uncertainty"]) == 365
+    np.testing.assert_allclose(rec["predictions"], z["target"], rtol=1e-5)   # inverse of the forward scaling
+    assert all(lo < m < hi for lo, m, hi in zip(rec["lower"], rec["predictions"], rec["upper"]))
+    rec2 = pipeline.bayesian_record(ys.rename(None), torch.full((365,), 0.1), y, sy)
+    assert set(rec2) == {"predictions", "uncertainty", "metrics"}            # main.py:192-196 keys only
+    res = {"feature_dates": {}, "actual": y.tolist(), "predictions": {"baseline": {"bayesian": rec2}}}
+    path = tmp_path / "results" / "model_results.json"
+    pipeline.save_results(res, str(path))
+    back = json.loads(path.read_text())
+    assert back["predictions"]["baseline"]["bayesian"]["metrics"]["rmse"] == rec2["metrics"]["rmse"]
+    if not torch.cuda.is_available():  # main.py:225-226
+        with pytest.raises(RuntimeError):
+            pipeline.train_and_evaluate_all(torch.from_numpy(z["features"]), torch.from_numpy(z["temporal"]), y)
