@@ -8,8 +8,9 @@ Workload (BASELINE.json configs[2], SURVEY.md 8d "Config 3"): 10,000 synthetic s
 steps (X [3,650,000, 11], standardised, resident in HBM before the timed region), 8 members x
 1024 MC samples, bf16 MFMA operands / fp32 accumulate, Philox weight noise, mean + unbiased std
 + 95 % interval from the streaming histogram.  One step = one full predict = 2.99e10 units.
-With N > 1 the 8,192 (member, sample) pairs are sharded over the ranks and the partial
-(sum, sumsq, histogram) are all-reduced over RCCL: total work is fixed -> "strong" scaling.
+With N > 1 the 8,192 (member, sample) pairs are sharded over the ranks; the partial (sum, sumsq,
+histogram) are reduce-scattered over rows on RCCL, each rank finalizes its row slice and the
+results are all-gathered: total work is fixed -> "strong" scaling.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (forward_bf16_kernel):
 algorithmic FLOPs (87,680 per unit) / launch duration measured with events on
@@ -95,6 +96,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("MCMC_BENCH_HANG_S"):  # debugging aid: a hang dumps every thread's stack and exits
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MCMC_BENCH_HANG_S"]), exit=True)
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,10 +107,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(f"--gpus {args.gpus} needs a launcher: python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MCMC_BENCH_BACKEND=gloo: rehearsal of the multi-rank host logic on a box with fewer GPUs than ranks
+    backend = os.environ.get("MCMC_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from mcmc_amd import mc_predict, pack_members
     from mcmc_amd.data import make_series_batch

@@ -157,7 +157,7 @@ def _combine_worker(rank, world, port, tmp):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from mcmc_amd.engine import ReduceState, combine_partials, shard_pairs
+        from mcmc_amd.engine import ReduceState, combine_partials, gather_rows, row_slice, scatter_combine, shard_pairs
         rng = np.random.default_rng(0)
         N, B, nbins = 64, 33, 128
         Y = (rng.normal(size=(N, B)) * 1.5 + rng.normal(size=B)).astype(np.float32)  # all "samples", same on both ranks
@@ -173,6 +173,7 @@ def _combine_worker(rank, world, port, tmp):
         st = ReduceState(e - b, torch.from_numpy(mine.astype(np.float64).sum(0)),
                          torch.from_numpy((mine.astype(np.float64) ** 2).sum(0)), torch.from_numpy(hist.copy()),
                          torch.from_numpy(lo), torch.from_numpy(inv_w), nbins)
+        part0 = ReduceState(st.n, st.sum.clone(), st.sumsq.clone(), st.hist.clone(), st.lo, st.inv_w, nbins)
         st = combine_partials(st)
         assert st.n == N
         full_hist = orc.hist_accumulate(Y, lo, inv_w, nbins)
@@ -183,20 +184,35 @@ def _combine_worker(rank, world, port, tmp):
         assert np.allclose(mean, tm.numpy(), atol=1e-6) and np.allclose(std, ts.numpy(), rtol=1e-5)
         tq = torch.quantile(torch.from_numpy(Y), torch.tensor([0.025, 0.975]), dim=0).numpy()
         assert np.all(np.abs(q - tq) <= 1.0 / inv_w[None, :])
+        # the product's exchange: reduce-scatter over rows -> finalize own slice -> all-gather
+        part, r0, r1 = scatter_combine(part0)
+        assert (r0, r1) == row_slice(B, rank, world)[:2] and part.n == N and part.sum.shape[0] == r1 - r0
+        # fp64 sums: same addends, possibly another association than the all-reduce's
+        assert torch.allclose(part.sum, st.sum[r0:r1], rtol=1e-14, atol=0) and torch.allclose(part.sumsq, st.sumsq[r0:r1], rtol=1e-14, atol=0)
+        assert torch.equal(part.hist, st.hist[r0:r1]) and part.hist.dtype == torch.int16
+        pm, ps, pq = orc.finalize_from_state(part.n, part.sum.numpy(), part.sumsq.numpy(),
+                                             part.hist.numpy().view(np.uint16).astype(np.int64), part.lo.numpy(), part.inv_w.numpy(),
+                                             (0.025, 0.975))
+        gm, gs, gq, none = gather_rows([torch.from_numpy(np.asarray(pm, dtype=np.float32)), torch.from_numpy(np.asarray(ps, dtype=np.float32)),
+                                        torch.from_numpy(np.asarray(pq, dtype=np.float32)), None], B)
+        assert none is None and gm.shape == (B,) and gq.shape == (2, B)
+        assert np.allclose(gm.numpy(), mean, rtol=1e-6, atol=1e-7) and np.allclose(gs.numpy(), std, rtol=1e-6)
+        assert np.array_equal(gq.numpy(), np.asarray(q, dtype=np.float32))   # histogram counts are exact
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
 
 
-def test_combine_partials_world2_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_combine_partials_gloo(tmp_path, world):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_combine_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    mp.spawn(_combine_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
 def test_combine_is_identity_without_process_group():

@@ -1,0 +1,79 @@
+"""Multi-rank rehearsal of the sharded predictive path and the data-parallel loss.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/check_multirank.py
+
+One rank per GPU over RCCL when the node has enough GPUs; on a one-GPU box the ranks share the
+card and talk over gloo (rehearsal of the host logic with real kernels).  Every rank compares the
+sharded result with its own single-rank run of the same job (Philox noise is keyed by global pair
+id, so only the fp64 association and the pilot's histogram edges may differ).
+"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcmc_amd import engine  # noqa: E402
+from mcmc_amd.loss import peak_weighted_loss  # noqa: E402
+
+
+def main():
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("MCMC_CHECK_TIMEOUT", "100")), exit=True)  # a hang names its line
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    ngpu = torch.cuda.device_count()
+    backend = "nccl" if ngpu >= world else "gloo"
+    dev = torch.device("cuda", local % ngpu)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    solo = None
+    for r in range(world):  # every rank must take part in every new_group call
+        g = dist.new_group([r])
+        if r == rank:
+            solo = g
+    g = torch.Generator().manual_seed(1)
+    B, F, M, S = int(os.environ.get("MCMC_CHECK_ROWS", "1003")), 11, 3, 40
+    P = engine.param_count(F)
+    X = torch.randn(B, F, generator=g).to(dev)
+    mu = (torch.randn(M, P, generator=g) * 0.08).to(dev)
+    rho = (-3.0 + 0.3 * torch.randn(M, P, generator=g)).to(dev)
+    q = (0.025, 0.5, 0.975)
+    for dtype, tol in (("fp32", 2e-6), ("bf16", 2e-6)):
+        shard = engine.mc_predict(X, mu, rho, S, dtype=dtype, seed=11, q_levels=q, chunk_pairs=16)
+        alone = engine.mc_predict(X, mu, rho, S, dtype=dtype, seed=11, q_levels=q, chunk_pairs=16, group=solo)
+        assert shard.n_samples == alone.n_samples == M * S
+        assert torch.allclose(shard.mean, alone.mean, rtol=tol, atol=tol), (dtype, float((shard.mean - alone.mean).abs().max()))
+        assert torch.allclose(shard.std, alone.std, rtol=10 * tol, atol=tol), (dtype, float((shard.std - alone.std).abs().max()))
+        # each estimate lies within one of ITS bins of the exact order statistic; the two runs place their
+        # bins from different pilots (first chunk of every rank vs first chunk of one), hence the sum
+        width = shard.bin_width + alone.bin_width
+        bad = ((shard.quantiles - alone.quantiles).abs() > width)
+        assert not bool(bad.any()), (dtype, int(bad.sum()), float(((shard.quantiles - alone.quantiles).abs() / width).max()))
+        # all ranks hold the same full result
+        ref = shard.mean.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, shard.mean)
+    # loss, rows split over ranks, global-batch statistics
+    N = 4099
+    t = torch.randn(N, generator=g)
+    p = t + 0.3 * torch.randn(N, generator=g)
+    per = (N + world - 1) // world
+    sl = slice(rank * per, min(N, (rank + 1) * per))
+    p_loc = p[sl].to(dev).requires_grad_(True)
+    loss = peak_weighted_loss(p_loc, t[sl].to(dev), group=None)
+    loss.backward()
+    p_all = p.to(dev).requires_grad_(True)
+    full = peak_weighted_loss(p_all, t.to(dev), group=False)
+    full.backward()
+    assert abs(float(loss) - float(full)) <= 2e-6 * abs(float(full)), (float(loss), float(full))
+    assert torch.allclose(p_loc.grad, p_all.grad[sl], rtol=1e-5, atol=1e-9)
+    dist.barrier()
+    if rank == 0:
+        print(f"multirank OK: world={world} backend={backend} gpus={ngpu}")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
