@@ -21,6 +21,11 @@ What is captured:
                       utils.evaluate_predictions on the config-1 series for several feature subsets
                       (main.py itself needs prophet, absent here: its few lines are re-run verbatim in
                       spirit by gen_glue below, on the reference's data.py output).
+  tft_fwd.npz         reference TemporalFusionTransformer (seeded init) on the config-1 scaled series:
+                      flat parameters, TFTModel.predict output [365] and the raw model output of a batch.
+  tft_train.npz       the reference's TFTModel.train run on CPU (2 epochs of a 32- and a 9-sequence
+                      batch): initial parameters, per step the batch, the 4 dropout keep-masks
+                      (torch.nn.functional.dropout wrapped), lr / beta1, loss; final parameters.
   train_steps.npz     the reference's own GPUBayesianEnsemble.train run on CPU (2 members, 2 epochs
                       of a 32-row and a 13-row batch, 2 samples): initial (mu, rho), and per step the
                       batch, eps, dropout masks, lr / beta1 the optimiser used, loss; final (mu, rho).
@@ -323,6 +328,75 @@ def gen_train_steps():
     np.savez_compressed(os.path.join(OUT, "train_steps.npz"), **out)
 
 
+def gen_tft():
+    from models.temporal_fusion import TFTModel  # reference
+    from oracle import tft_oracle as tft
+    _, _, Xs, ys, _, _ = make_cfg1_inputs(seed=2025)
+    F_in = Xs.shape[1]
+    torch.manual_seed(909)
+    ref = TFTModel(num_features=F_in, seq_length=30, batch_size=32, device="cpu")
+    with torch.no_grad():  # fresh LayerNorms are (1, 0) and biases small: make every term generic
+        for n, q in ref.model.named_parameters():
+            if "layer_norm" in n or n.endswith("bias"):
+                q.add_(0.1 * torch.randn_like(q))
+    flat = tft.flatten(dict(ref.model.named_parameters()), F_in)
+    preds = ref.predict(Xs)
+    seqs = ref.create_sequences(Xs).rename(None)
+    ref.model.eval()
+    with torch.no_grad():
+        raw = ref.model(seqs[100:105]).rename(None)
+    np.savez_compressed(os.path.join(OUT, "tft_fwd.npz"), X=Xs.numpy(), flat=flat.numpy(), predict=np.asarray(preds, dtype=np.float32),
+                        raw_batch=seqs[100:105].numpy(), raw_out=raw.numpy())
+
+    # ---- training trajectory: the reference's own train() with everything its RNG decided recorded
+    N, epochs = 70, 2                       # 41 sequences -> batches of 32 and 9
+    Xt, yt = Xs[:N].clone(), ys[:N].clone()
+    torch.manual_seed(910)
+    ref = TFTModel(num_features=F_in, seq_length=30, batch_size=32, device="cpu")
+    flat0 = tft.flatten(dict(ref.model.named_parameters()), F_in)
+    import models.temporal_fusion as ref_mod
+    import torch.nn.functional as Fn
+    masks, xbs, ybs, losses, lrs, beta1s = [], [], [], [], [], []
+    orig_drop, orig_loss, orig_step, orig_fwd = Fn.dropout, ref_mod.peak_weighted_loss, torch.optim.AdamW.step, ref.model.forward
+
+    def drop_wrap(x, p=0.5, training=True, inplace=False):
+        out = orig_drop(x, p, training, inplace)
+        if training and p > 0:
+            masks.append(torch.where(x != 0, (out != 0), torch.ones_like(out, dtype=torch.bool)).to(torch.uint8).clone())
+        return out
+
+    def loss_wrap(pr, t, *a, **k):
+        L = orig_loss(pr, t, *a, **k)
+        ybs.append(t.detach().clone())
+        losses.append(L.detach().clone())
+        return L
+
+    def step_wrap(self, *a, **k):
+        lrs.append(float(self.param_groups[0]["lr"]))
+        beta1s.append(float(self.param_groups[0]["betas"][0]))
+        return orig_step(self, *a, **k)
+
+    def fwd_wrap(x):
+        xbs.append(x.rename(None).detach().clone())
+        return orig_fwd(x)
+
+    Fn.dropout, ref_mod.peak_weighted_loss, torch.optim.AdamW.step, ref.model.forward = drop_wrap, loss_wrap, step_wrap, fwd_wrap
+    try:
+        torch.manual_seed(911)
+        ref.train(Xt, yt, epochs=epochs)
+    finally:
+        Fn.dropout, ref_mod.peak_weighted_loss, torch.optim.AdamW.step, ref.model.forward = orig_drop, orig_loss, orig_step, orig_fwd
+    n_steps = len(losses)
+    assert n_steps == epochs * 2 and len(masks) == 4 * n_steps and len(xbs) == n_steps
+    out = dict(X=Xt.numpy(), y=yt.numpy(), flat0=flat0.numpy(), flat1=tft.flatten(dict(ref.model.named_parameters()), F_in).numpy(),
+               lr=np.array(lrs), beta1=np.array(beta1s), loss=torch.stack(losses).numpy(), n_steps=n_steps)
+    for i in range(n_steps):
+        out[f"xb_{i}"], out[f"yb_{i}"] = xbs[i].numpy(), ybs[i].numpy()
+        for j in range(4):
+            out[f"mask{j}_{i}"] = masks[4 * i + j].numpy()
+    np.savez_compressed(os.path.join(OUT, "tft_train.npz"), **out)
+
+
 def gen_glue():
     from sklearn.preprocessing import StandardScaler
     from itertools import combinations
@@ -362,5 +436,6 @@ if __name__ == "__main__":
     gen_loss()
     gen_train_steps()
     gen_glue()
+    gen_tft()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
