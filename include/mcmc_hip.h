@@ -186,6 +186,40 @@ int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_
                       float weight_decay, float max_norm, int64_t step, float* gnorm,
                       mcmc_stream_t stream);
 
+/* ---- next row: the Temporal Fusion Transformer leg ------------------------ */
+/* models/temporal_fusion.py.  Parameters are ONE flat fp32 vector in the reference module's
+ * named_parameters() order (input_projection, feature_grn, temporal_grn, attention, final_grn,
+ * output_projection; 67,585 values at 11 features); PT is the same vector with every weight
+ * matrix transposed (mcmc_tft_transpose).  Windows are rows start[b] .. start[b]+seq_len-1 of
+ * X [n_rows, num_features] (TFTModel.create_sequences :167-203 without materialising them);
+ * seq_len <= 32; rows past n_rows (or an invalid start) read as zero.  Only the last timestep's output is produced - what train (:249) and predict
+ * (:293) read.  mask_mode: 0 eval, 1 host uint8 keep-masks in the reference's draw order
+ * (feature GRN [B,T,64], temporal GRN [B,T,64], attention [B*4,T,T], final GRN [B,T,64]),
+ * 2 Philox keyed (seed; window start, row, element). */
+int64_t mcmc_tft_param_count(int num_features);
+int mcmc_tft_transpose(mcmc_ctx* ctx, const float* P, float* PT, int num_features, mcmc_stream_t stream);
+/* TemporalFusionTransformer.forward (:120-153) + [:, -1, 0] -> pred [n_windows]. */
+int mcmc_tft_forward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len,
+                     int num_features, const float* P, const float* PT, int mask_mode,
+                     const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                     const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
+                     float p_drop, float* pred, mcmc_stream_t stream);
+/* loss.backward() (:252): recomputes the window's forward with the same masks; delta [n_windows]
+ * = dLoss/dpred (mcmc_train_loss with n_members = n_samples = 1); dP [n_windows, n_params] gets
+ * every window's parameter gradient (all entries written). */
+int mcmc_tft_backward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len,
+                      int num_features, const float* P, const float* PT, int mask_mode,
+                      const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                      const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
+                      float p_drop, const float* delta, float* dP, mcmc_stream_t stream);
+/* grad = sum over the n_partials rows of dP; clip_grad_norm_(max_norm) (:254); torch's AdamW step
+ * (:255) on a flat parameter vector.  norm_scratch: fp64 [mcmc_flat_norm_blocks()]. */
+int mcmc_flat_norm_blocks(void);
+int mcmc_flat_adamw(mcmc_ctx* ctx, float* param, int64_t n, const float* dP, int n_partials, float* grad,
+                    float* adam_m, float* adam_v, double* norm_scratch, float lr, float beta1,
+                    float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step,
+                    float* gnorm, mcmc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

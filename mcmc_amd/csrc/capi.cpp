@@ -34,7 +34,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 2; }
+int mcmc_abi_version(void) { return 3; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -296,6 +296,75 @@ int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_
     MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
     return launch_train_update(mu, rho, sigma, n_members, n_samples, input_dim, eps, dW, gmu, grho, adam_m, adam_v, norm_scratch, active,
                                lr, beta1, beta2, adam_eps, weight_decay, max_norm, step, gnorm, (hipStream_t)stream);
+}
+
+// ---- TFT (row f4) ---------------------------------------------------------------------------------------
+static int check_tft(int n_windows, int seq_len, int num_features) {
+    MCMC_REQUIRE(num_features >= 1 && num_features <= kMaxInputDim, "num_features must be in [1, %d] (got %d)", kMaxInputDim, num_features);
+    MCMC_REQUIRE(seq_len >= 1 && seq_len <= 32, "seq_len must be in [1, 32] (got %d)", seq_len);
+    MCMC_REQUIRE(n_windows >= 0, "n_windows < 0");
+    return MCMC_OK;
+}
+
+static int check_tft_masks(int mask_mode, const uint8_t* a, const uint8_t* b, const uint8_t* c, const uint8_t* d, float p_drop) {
+    MCMC_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "mask_mode must be 0 (eval), 1 (host) or 2 (philox)");
+    MCMC_REQUIRE(mask_mode != 1 || (a && b && c && d), "mask_mode 1 needs all four masks");
+    MCMC_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "p_drop must be in [0, 1)");
+    return MCMC_OK;
+}
+
+int64_t mcmc_tft_param_count(int num_features) {
+    if (num_features < 1 || num_features > kMaxInputDim) return set_error(MCMC_EINVAL, "num_features must be in [1, %d]", kMaxInputDim);
+    return tft_params(num_features);
+}
+
+int mcmc_tft_transpose(mcmc_ctx* ctx, const float* P, float* PT, int num_features, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_tft(0, 1, num_features)) return rc;
+    MCMC_REQUIRE(P && PT && P != PT, "P / PT is NULL or aliased");
+    return launch_tft_transpose(P, PT, num_features, (hipStream_t)stream);
+}
+
+int mcmc_tft_forward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len, int num_features, const float* P,
+                     const float* PT, int mask_mode, const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                     const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed, float p_drop, float* pred,
+                     mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_tft(n_windows, seq_len, num_features)) return rc;
+    if (int rc = check_tft_masks(mask_mode, mask_feature, mask_temporal, mask_attention, mask_final, p_drop)) return rc;
+    if (n_windows == 0) return MCMC_OK;
+    MCMC_REQUIRE(X && start && P && PT && pred, "NULL pointer");
+    MCMC_REQUIRE(n_rows >= seq_len, "X has %lld rows, fewer than seq_len %d", (long long)n_rows, seq_len);
+    return launch_tft_forward(X, n_rows, start, n_windows, seq_len, num_features, P, PT, mask_mode, mask_feature, mask_temporal, mask_attention,
+                              mask_final, seed, p_drop, pred, (hipStream_t)stream);
+}
+
+int mcmc_tft_backward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len, int num_features, const float* P,
+                      const float* PT, int mask_mode, const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                      const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed, float p_drop, const float* delta, float* dP,
+                      mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_tft(n_windows, seq_len, num_features)) return rc;
+    if (int rc = check_tft_masks(mask_mode, mask_feature, mask_temporal, mask_attention, mask_final, p_drop)) return rc;
+    if (n_windows == 0) return MCMC_OK;
+    MCMC_REQUIRE(X && start && P && PT && delta && dP, "NULL pointer");
+    MCMC_REQUIRE(n_rows >= seq_len, "X has %lld rows, fewer than seq_len %d", (long long)n_rows, seq_len);
+    return launch_tft_backward(X, n_rows, start, n_windows, seq_len, num_features, P, PT, mask_mode, mask_feature, mask_temporal, mask_attention,
+                               mask_final, seed, p_drop, delta, dP, (hipStream_t)stream);
+}
+
+int mcmc_flat_norm_blocks(void) { return tft_flat_blocks(); }
+
+int mcmc_flat_adamw(mcmc_ctx* ctx, float* param, int64_t n, const float* dP, int n_partials, float* grad, float* adam_m, float* adam_v,
+                    double* norm_scratch, float lr, float beta1, float beta2, float adam_eps, float weight_decay, float max_norm,
+                    int64_t step, float* gnorm, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n >= 1 && n_partials >= 1, "n and n_partials must be >= 1");
+    MCMC_REQUIRE(param && dP && grad && adam_m && adam_v && norm_scratch, "NULL pointer");
+    MCMC_REQUIRE(step >= 1, "step is 1-based");
+    MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
+    return launch_flat_update(param, n, dP, n_partials, grad, adam_m, adam_v, norm_scratch, lr, beta1, beta2, adam_eps, weight_decay,
+                              max_norm, step, gnorm, (hipStream_t)stream);
 }
 
 }  // extern "C"

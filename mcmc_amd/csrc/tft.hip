@@ -1,0 +1,711 @@
+// Row f4: the Temporal Fusion Transformer leg on the device.
+//
+// Restates /root/reference/models/temporal_fusion.py for gfx950:
+//   TemporalFusionTransformer.forward  :120-153  input projection -> feature GRN -> temporal GRN ->
+//       nn.MultiheadAttention(64, 4 heads, dropout 0.1) -> final GRN -> Linear(64 -> 1)
+//   GatedResidualNetwork.forward       :62-89    fc1 -> ELU -> dropout -> fc2 -> ELU; gate = sigmoid(W[x;h]);
+//       LayerNorm(gate*h + (1-gate)*x)
+//   TFTModel.train inner step          :242-256  prediction = output[:, -1, 0]
+//   TFTModel.predict                   :289-294  same read-out in eval mode
+// Both callers read only the LAST timestep of every window.  The two leading GRNs and the key /
+// value projections need all T rows, but the attention query, the output projection, the final
+// GRN and the read-out are evaluated for the last row only - the gradient is the same and the
+// reference's [T x T] attention collapses to one query per head.
+//
+// One workgroup (4 waves) owns one window; wave w owns rows 8w..8w+7 and lane = feature, so a
+// LayerNorm row statistic is one wave reduction and every dense layer is a per-wave [8 x 64] tile
+// whose inputs are broadcast LDS reads.  All activations the backward pass needs stay in LDS
+// (153 KB); weights stream from L2 in two layouts (P [out][in] for input gradients, PT [in][out]
+// for the forward) so every global access is lane-contiguous.  fp32 VALU arithmetic: windows are
+// 30 x 64, the step is launch/latency bound.
+#include "common.hpp"
+#include "philox.hpp"
+
+namespace mcmc {
+
+namespace {
+
+constexpr int HD = 64;     // hidden size (temporal_fusion.py:160)
+constexpr int NH = 4;      // heads (:161)
+constexpr int DH = HD / NH;
+constexpr int TMAX = 32;   // rows per window tile (seq_length 30, :157)
+constexpr int NT = 256;
+constexpr int XS = 28;     // LDS stride of the input window (>= kMaxInputDim, multiple of 4)
+constexpr float kLnEps = 1e-5f;
+
+// ---- flat parameter layout: the reference module's named_parameters() order --------------------
+constexpr int kGrnW1 = 0, kGrnB1 = 4096, kGrnW2 = 4160, kGrnB2 = 8256, kGrnWg = 8320, kGrnBg = 16512, kGrnGamma = 16576,
+              kGrnBeta = 16640, kGrnSize = 16704;
+constexpr int kAttInW = 0, kAttInB = 12288, kAttOutW = 12480, kAttOutB = 16576, kAttSize = 16640;
+__host__ __device__ inline int tft_off_proj_b(int F) { return 64 * F; }
+__host__ __device__ inline int tft_off_grn(int F, int g) { return 64 * F + 64 + (g < 2 ? g * kGrnSize : 2 * kGrnSize + kAttSize); }
+__host__ __device__ inline int tft_off_att(int F) { return 64 * F + 64 + 2 * kGrnSize; }
+__host__ __device__ inline int tft_off_out(int F) { return 64 * F + 64 + 3 * kGrnSize + kAttSize; }
+__host__ __device__ inline int tft_param_count(int F) { return tft_off_out(F) + 65; }
+
+struct TftMasks {
+    const uint8_t* g[3];  // GRN keep masks [B,T,64] (feature, temporal, final) or null
+    const uint8_t* at;    // attention keep mask [B*heads,T,T] or null
+    uint64_t seed;
+    int mode;             // 0 none (eval), 1 host, 2 philox
+    float keep_prob, scale;
+};
+
+struct Win {              // one window
+    int b;                // index in the batch (host masks)
+    uint32_t key;         // Philox key: the window's start row (independent of batch composition)
+    int T;
+};
+
+__device__ __forceinline__ bool keep_grn(const TftMasks& ms, const Win& w, int which, int r, int o) {
+    if (ms.mode == 1) return ms.g[which][((int64_t)w.b * w.T + r) * HD + o] != 0;
+    return philox_mask_uniform(ms.seed, w.key, (uint32_t)r, (uint32_t)(which * HD + o)) < ms.keep_prob;
+}
+__device__ __forceinline__ bool keep_att(const TftMasks& ms, const Win& w, int h, int j) {
+    if (ms.mode == 1) return ms.at[(((int64_t)w.b * NH + h) * w.T + (w.T - 1)) * w.T + j] != 0;
+    return philox_mask_uniform(ms.seed, w.key, (uint32_t)(w.T - 1), (uint32_t)(3 * HD + h * TMAX + j)) < ms.keep_prob;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float elu(float z) { return z > 0.0f ? z : expm1f(z); }
+__device__ __forceinline__ float sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
+// derivative factor of a stored ELU(+dropout) activation; masked elements are stored as -0.0f
+__device__ __forceinline__ float dfactor(float h, float scale) {
+    if (__float_as_uint(h) == 0x80000000u) return 0.0f;
+    return h > 0.0f ? scale : h + scale;
+}
+
+// acc[rr] += sum_{j<J} in[(row0+rr)*stride + j] * Mat[j*ld + c]   (J multiple of 4; `in` in LDS, broadcast reads)
+template <int J>
+__device__ __forceinline__ void dense8(const float* in, int stride, int row0, const float* __restrict__ Mat, int ld, int c,
+                                       float (&acc)[8]) {
+#pragma unroll 2
+    for (int j = 0; j < J; j += 4) {
+        const float w0 = Mat[(j + 0) * ld + c], w1 = Mat[(j + 1) * ld + c], w2 = Mat[(j + 2) * ld + c], w3 = Mat[(j + 3) * ld + c];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const float4 v = *reinterpret_cast<const float4*>(in + (row0 + rr) * stride + j);
+            acc[rr] = fmaf(v.x, w0, acc[rr]);
+            acc[rr] = fmaf(v.y, w1, acc[rr]);
+            acc[rr] = fmaf(v.z, w2, acc[rr]);
+            acc[rr] = fmaf(v.w, w3, acc[rr]);
+        }
+    }
+}
+
+// ---- LDS ------------------------------------------------------------------------------------------------
+struct GrnBuf {
+    float *h1, *h2, *gt, *xh, *rstd;  // [rows][64] x4, [rows]
+};
+struct Lds {
+    float* x;    // [32][XS]
+    float* u[3]; // inputs of GRN 0, 1 and of the attention: [32][64]
+    GrnBuf g[3]; // g[2] has 8 rows
+    float *K, *V;             // [32][64]
+    float *qs, *prob, *probd, *ctx;  // [64], [4][32], [4][32], [64]
+    float* a_out;  // attention output = input of the final GRN: [8][64], row 0 live
+    float* out3;   // final GRN output [8][64], row 0 live
+    // backward scratch
+    float *dU, *dz, *dzT;  // [32][64], [32][64], [64][32]
+    float* red;            // [4][64] cross-wave sums
+    float *vec0, *vec1;    // [64] small vectors (do / dctx, dq)
+    float* ds;             // [4][32]
+};
+constexpr int kLdsFloats = TMAX * XS + 3 * TMAX * HD + 2 * (4 * TMAX * HD + TMAX) + (4 * 8 * HD + 8) + 2 * TMAX * HD + (HD + 2 * NH * TMAX + HD) +
+                           2 * 8 * HD + 3 * TMAX * HD + 4 * HD + 2 * HD + NH * TMAX;
+
+__device__ __forceinline__ Lds carve(float* p) {
+    Lds l;
+    auto take = [&](int n) { float* q = p; p += n; return q; };
+    l.x = take(TMAX * XS);
+    for (int i = 0; i < 3; ++i) l.u[i] = take(TMAX * HD);
+    for (int i = 0; i < 3; ++i) {
+        const int rows = i < 2 ? TMAX : 8;
+        l.g[i].h1 = take(rows * HD);
+        l.g[i].h2 = take(rows * HD);
+        l.g[i].gt = take(rows * HD);
+        l.g[i].xh = take(rows * HD);
+        l.g[i].rstd = take(rows);
+    }
+    l.K = take(TMAX * HD);
+    l.V = take(TMAX * HD);
+    l.qs = take(HD);
+    l.prob = take(NH * TMAX);
+    l.probd = take(NH * TMAX);
+    l.ctx = take(HD);
+    l.a_out = take(8 * HD);
+    l.out3 = take(8 * HD);
+    l.dU = take(TMAX * HD);
+    l.dz = take(TMAX * HD);
+    l.dzT = take(HD * TMAX);
+    l.red = take(4 * HD);
+    l.vec0 = take(HD);
+    l.vec1 = take(HD);
+    l.ds = take(NH * TMAX);
+    return l;
+}
+
+// ---- GRN forward on a row tile: wave `wv` owns rows 8wv..8wv+7 when wv < n_waves --------------------
+// u -> out (both [rows][64] in LDS); stores h1 (post dropout), h2, gate, xhat, rstd for the backward pass.
+// `row_of(r)` gives the window row of tile row r (masks); `live(r)` whether the row exists.
+template <bool TRAIN>
+__device__ __forceinline__ void grn_forward(const float* u, const GrnBuf& gb, float* out, const float* __restrict__ PT, int n_waves,
+                                            const TftMasks& ms, const Win& w, int which, int row_shift, int n_live) {
+    const int o = threadIdx.x & 63, wv = threadIdx.x >> 6, r0 = wv * 8;
+    const bool act = wv < n_waves;
+    float acc[8];
+    if (act) {
+        const float b = PT[kGrnB1 + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
+        dense8<HD>(u, HD, r0, PT + kGrnW1, HD, o, acc);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = r0 + rr;
+            float h = elu(acc[rr]);
+            if (TRAIN && ms.mode != 0) h = (r < n_live && keep_grn(ms, w, which, r + row_shift, o)) ? h * ms.scale : -0.0f;
+            gb.h1[r * HD + o] = r < n_live ? h : -0.0f;
+        }
+    }
+    __syncthreads();
+    float h2v[8];
+    if (act) {
+        const float b = PT[kGrnB2 + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
+        dense8<HD>(gb.h1, HD, r0, PT + kGrnW2, HD, o, acc);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            h2v[rr] = r0 + rr < n_live ? elu(acc[rr]) : 0.0f;
+            gb.h2[(r0 + rr) * HD + o] = h2v[rr];
+        }
+    }
+    __syncthreads();
+    if (act) {
+        const float b = PT[kGrnBg + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
+        dense8<HD>(u, HD, r0, PT + kGrnWg, HD, o, acc);               // gate input = [u | h2]  (transposed gate: [128][64])
+        dense8<HD>(gb.h2, HD, r0, PT + kGrnWg + HD * HD, HD, o, acc);
+        const float gamma = PT[kGrnGamma + o], beta = PT[kGrnBeta + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = r0 + rr;
+            const float g = sigmoidf(acc[rr]);
+            const float uv = u[r * HD + o];
+            const float wgt = g * h2v[rr] + (1.0f - g) * uv;
+            const float mean = wave_sum(wgt) * (1.0f / HD);
+            const float d = wgt - mean;
+            const float var = wave_sum(d * d) * (1.0f / HD);
+            const float rstd = 1.0f / sqrtf(var + kLnEps);
+            const float xh = d * rstd;
+            gb.gt[r * HD + o] = g;
+            gb.xh[r * HD + o] = xh;
+            if (o == 0) gb.rstd[r] = rstd;
+            out[r * HD + o] = r < n_live ? fmaf(xh, gamma, beta) : 0.0f;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- whole forward of one window; returns the prediction in every thread -----------------------------
+template <bool TRAIN>
+__device__ __forceinline__ float tft_forward_window(const Lds& l, const float* __restrict__ xw, int64_t rows_left, int F, const float* __restrict__ P,
+                                                    const float* __restrict__ PT, const TftMasks& ms, const Win& w) {
+    const int t = threadIdx.x, o = t & 63, wv = t >> 6, r0 = wv * 8, T = w.T;
+    for (int i = t; i < TMAX * XS; i += NT) {
+        const int r = i / XS, k = i % XS;
+        l.x[i] = (r < T && k < F && r < rows_left) ? xw[(int64_t)r * F + k] : 0.0f;  // rows past the end of X read as 0
+    }
+    __syncthreads();
+    {  // input projection (:130)
+        float acc[8];
+        const float b = PT[tft_off_proj_b(F) + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
+        for (int k = 0; k < F; ++k) {
+            const float wk = PT[k * HD + o];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) acc[rr] = fmaf(l.x[(r0 + rr) * XS + k], wk, acc[rr]);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) l.u[0][(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
+    }
+    __syncthreads();
+    grn_forward<TRAIN>(l.u[0], l.g[0], l.u[1], PT + tft_off_grn(F, 0), 4, ms, w, 0, 0, T);
+    grn_forward<TRAIN>(l.u[1], l.g[1], l.u[2], PT + tft_off_grn(F, 1), 4, ms, w, 1, 0, T);
+    // ---- attention (:139-144), query = last row only
+    const float* A = PT + tft_off_att(F);  // transposed in_proj: [64][192]; out_proj [64][64]
+    {
+        float acc[8];
+        float b = A[kAttInB + HD + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
+        dense8<HD>(l.u[2], HD, r0, A + kAttInW + HD, 3 * HD, o, acc);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) l.K[(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
+        b = A[kAttInB + 2 * HD + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
+        dense8<HD>(l.u[2], HD, r0, A + kAttInW + 2 * HD, 3 * HD, o, acc);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) l.V[(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
+        if (wv == 0) {
+            float q = A[kAttInB + o];
+            const float* ul = l.u[2] + (T - 1) * HD;
+            for (int k = 0; k < HD; ++k) q = fmaf(ul[k], A[kAttInW + k * 3 * HD + o], q);
+            l.qs[o] = q * 0.25f;  // q * sqrt(1/head_dim), head_dim = 16
+        }
+    }
+    __syncthreads();
+    if (t < NH * TMAX) {  // scores + softmax: 32 lanes per head
+        const int h = t >> 5, j = t & 31;
+        float s = -INFINITY;
+        if (j < T) {
+            s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s = fmaf(l.qs[h * DH + c], l.K[j * HD + h * DH + c], s);
+        }
+        float m = s;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float e = j < T ? expf(s - m) : 0.0f;
+        float sum = e;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        const float a = e / sum;
+        l.prob[t] = a;
+        float ad = a;
+        if (TRAIN && ms.mode != 0) ad = (j < T && keep_att(ms, w, h, j)) ? a * ms.scale : 0.0f;
+        l.probd[t] = ad;
+    }
+    __syncthreads();
+    if (t < HD) {
+        const int h = t >> 4;
+        float c = 0.0f;
+        for (int j = 0; j < T; ++j) c = fmaf(l.probd[h * TMAX + j], l.V[j * HD + t], c);
+        l.ctx[t] = c;
+    }
+    __syncthreads();
+    for (int i = t; i < 8 * HD; i += NT) {
+        float v = 0.0f;
+        if (i < HD) {
+            v = A[kAttOutB + i];
+            for (int c = 0; c < HD; ++c) v = fmaf(l.ctx[c], A[kAttOutW + c * HD + i], v);
+        }
+        l.a_out[i] = v;
+    }
+    __syncthreads();
+    // final GRN on the last row (tile row 0 <-> window row T-1)
+    grn_forward<TRAIN>(l.a_out, l.g[2], l.out3, PT + tft_off_grn(F, 2), 1, ms, w, 2, T - 1, 1);
+    const float* Wo = P + tft_off_out(F);
+    float y = wave_sum(l.out3[o] * Wo[o]) + Wo[HD];
+    return y;
+}
+
+// ---- backward helpers ---------------------------------------------------------------------------------------
+// dW[o][col0 + k] = sum_{r<R} dzT[o][r] * act[r*stride + k]  for the 16 o's of this wave; written (not added) to g
+template <int R>
+__device__ __forceinline__ void wgrad(const float* dzT, const float* act, int stride, int kmax, float* __restrict__ g, int ld, int col0) {
+    const int k = threadIdx.x & 63, og = threadIdx.x >> 6;
+    if (k >= kmax) return;
+    float a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = act[r * stride + k];
+#pragma unroll 1
+    for (int o = og * 16; o < og * 16 + 16; ++o) {
+        float s = 0.0f;
+#pragma unroll
+        for (int r4 = 0; r4 < R; r4 += 4) {
+            const float4 z = *reinterpret_cast<const float4*>(dzT + o * TMAX + r4);
+            s = fmaf(z.x, a[r4], s);
+            s = fmaf(z.y, a[r4 + 1], s);
+            s = fmaf(z.z, a[r4 + 2], s);
+            s = fmaf(z.w, a[r4 + 3], s);
+        }
+        g[o * ld + col0 + k] = s;
+    }
+}
+// bias gradient: g[o] = sum_r dzT[o][r]
+template <int R>
+__device__ __forceinline__ void bgrad(const float* dzT, float* __restrict__ g) {
+    if (threadIdx.x < HD) {
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) s += dzT[threadIdx.x * TMAX + r];
+        g[threadIdx.x] = s;
+    }
+}
+// store a per-thread [8] tile into dz (row-major) and dzT (transposed); inactive waves store zeros
+__device__ __forceinline__ void store_dz(const Lds& l, const float (&v)[8], bool act) {
+    const int o = threadIdx.x & 63, r0 = (threadIdx.x >> 6) * 8;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const float x = act ? v[rr] : 0.0f;
+        l.dz[(r0 + rr) * HD + o] = x;
+        l.dzT[o * TMAX + r0 + rr] = x;
+    }
+}
+
+// GRN backward: upstream l.dU (gradient w.r.t. the GRN output) -> l.dU (gradient w.r.t. its input u).
+template <int R>
+__device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const GrnBuf& gb, const float* __restrict__ Pg, float* __restrict__ G,
+                                             int n_waves, float scale) {
+    const int o = threadIdx.x & 63, wv = threadIdx.x >> 6, r0 = wv * 8;
+    const bool act = wv < n_waves;
+    float du[8], dh2[8], tmp[8];
+    float dgam = 0.0f, dbet = 0.0f;
+    if (act) {
+        const float gamma = Pg[kGrnGamma + o];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = r0 + rr;
+            const float dy = l.dU[r * HD + o], xh = gb.xh[r * HD + o];
+            dgam = fmaf(dy, xh, dgam);
+            dbet += dy;
+            const float dxh = dy * gamma;
+            const float m1 = wave_sum(dxh) * (1.0f / HD);
+            const float m2 = wave_sum(dxh * xh) * (1.0f / HD);
+            const float dw = gb.rstd[r] * (dxh - m1 - xh * m2);
+            const float g = gb.gt[r * HD + o], h2v = gb.h2[r * HD + o], uv = u[r * HD + o];
+            tmp[rr] = dw * (h2v - uv) * g * (1.0f - g);  // d gate pre-activation
+            dh2[rr] = dw * g;
+            du[rr] = dw * (1.0f - g);
+        }
+    }
+    l.red[wv * HD + o] = act ? dgam : 0.0f;
+    store_dz(l, tmp, act);
+    __syncthreads();
+    if (threadIdx.x < HD) G[kGrnGamma + o] = l.red[o] + l.red[HD + o] + l.red[2 * HD + o] + l.red[3 * HD + o];
+    __syncthreads();
+    l.red[wv * HD + o] = act ? dbet : 0.0f;
+    // gate: dWg = dgp^T [u | h2], dbg; d[u | h2] += dgp Wg
+    wgrad<R>(l.dzT, u, HD, HD, G + kGrnWg, 2 * HD, 0);
+    wgrad<R>(l.dzT, gb.h2, HD, HD, G + kGrnWg, 2 * HD, HD);
+    bgrad<R>(l.dzT, G + kGrnBg);
+    if (act) {
+        dense8<HD>(l.dz, HD, r0, Pg + kGrnWg, 2 * HD, o, du);
+        dense8<HD>(l.dz, HD, r0, Pg + kGrnWg + HD, 2 * HD, o, dh2);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const float h2v = gb.h2[(r0 + rr) * HD + o];
+            tmp[rr] = dh2[rr] * (h2v > 0.0f ? 1.0f : h2v + 1.0f);  // d a2
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < HD) G[kGrnBeta + o] = l.red[o] + l.red[HD + o] + l.red[2 * HD + o] + l.red[3 * HD + o];
+    store_dz(l, tmp, act);
+    __syncthreads();
+    wgrad<R>(l.dzT, gb.h1, HD, HD, G + kGrnW2, HD, 0);
+    bgrad<R>(l.dzT, G + kGrnB2);
+    if (act) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) tmp[rr] = 0.0f;
+        dense8<HD>(l.dz, HD, r0, Pg + kGrnW2, HD, o, tmp);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) tmp[rr] *= dfactor(gb.h1[(r0 + rr) * HD + o], scale);  // d a1
+    }
+    __syncthreads();
+    store_dz(l, tmp, act);
+    __syncthreads();
+    wgrad<R>(l.dzT, u, HD, HD, G + kGrnW1, HD, 0);
+    bgrad<R>(l.dzT, G + kGrnB1);
+    if (act) {
+        dense8<HD>(l.dz, HD, r0, Pg + kGrnW1, HD, o, du);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) l.dU[(r0 + rr) * HD + o] = du[rr];
+    }
+    __syncthreads();
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tft_transpose_kernel(const float* __restrict__ P, float* __restrict__ PT, int F) {
+    const int n = tft_param_count(F);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        // find the matrix this element belongs to: (base, rows=out, cols=in) or a vector
+        int base = 0, rows = 0, cols = 0;
+        auto in_mat = [&](int b, int r, int c) {
+            if (i >= b && i < b + r * c) {
+                base = b;
+                rows = r;
+                cols = c;
+                return true;
+            }
+            return false;
+        };
+        bool m = in_mat(0, HD, F);
+        for (int g = 0; g < 3 && !m; ++g) {
+            const int gb = tft_off_grn(F, g);
+            m = in_mat(gb + kGrnW1, HD, HD) || in_mat(gb + kGrnW2, HD, HD) || in_mat(gb + kGrnWg, HD, 2 * HD);
+        }
+        if (!m) m = in_mat(tft_off_att(F) + kAttInW, 3 * HD, HD) || in_mat(tft_off_att(F) + kAttOutW, HD, HD);
+        int j = i;
+        if (m) {
+            const int e = i - base, r = e / cols, c = e % cols;
+            j = base + c * rows + r;
+        }
+        PT[j] = P[i];
+    }
+}
+
+template <bool TRAIN>
+__global__ __launch_bounds__(NT, 1) void tft_forward_kernel(const float* __restrict__ X, int64_t n_rows, const int* __restrict__ start, int T, int F,
+                                                            const float* __restrict__ P, const float* __restrict__ PT, TftMasks ms,
+                                                            float* __restrict__ pred) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Lds l = carve(smem);
+    Win w;
+    w.b = blockIdx.x;
+    w.key = (uint32_t)start[blockIdx.x];
+    w.T = T;
+    int64_t s0 = start[blockIdx.x];
+    if (s0 < 0 || s0 > n_rows) s0 = n_rows;  // an invalid start reads an all-zero window instead of faulting
+    const float y = tft_forward_window<TRAIN>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
+    if (threadIdx.x == 0) pred[blockIdx.x] = y;
+}
+
+__global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __restrict__ X, int64_t n_rows, const int* __restrict__ start, int T, int F,
+                                                             const float* __restrict__ P, const float* __restrict__ PT, TftMasks ms,
+                                                             const float* __restrict__ delta, float* __restrict__ dP) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Lds l = carve(smem);
+    Win w;
+    w.b = blockIdx.x;
+    w.key = (uint32_t)start[blockIdx.x];
+    w.T = T;
+    const int t = threadIdx.x, o = t & 63, wv = t >> 6, r0 = wv * 8;
+    int64_t s0 = start[blockIdx.x];
+    if (s0 < 0 || s0 > n_rows) s0 = n_rows;
+    tft_forward_window<true>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
+    float* G = dP + (int64_t)blockIdx.x * tft_param_count(F);
+    const float sc = ms.mode != 0 ? ms.scale : 1.0f;
+    const float dy = delta[blockIdx.x];
+    // ---- read-out (:149-150, last row): dWout, dbout, upstream of the final GRN in tile row 0
+    {
+        const float* Wo = P + tft_off_out(F);
+        float* Go = G + tft_off_out(F);
+        if (t < HD) Go[t] = dy * l.out3[t];
+        if (t == HD) Go[HD] = dy;
+        for (int i = t; i < TMAX * HD; i += NT) l.dU[i] = i < HD ? dy * Wo[i] : 0.0f;
+    }
+    __syncthreads();
+    grn_backward<8>(l, l.a_out, l.g[2], P + tft_off_grn(F, 2), G + tft_off_grn(F, 2), 1, sc);
+    // ---- attention backward; l.dU row 0 = gradient w.r.t. the attention output of the last row
+    const float* A = P + tft_off_att(F);
+    float* GA = G + tft_off_att(F);
+    if (t < HD) {
+        const float d_o = l.dU[t];
+        l.vec0[t] = d_o;
+        GA[kAttOutB + t] = d_o;
+    }
+    __syncthreads();
+    {  // dWo[o][c] = do[o] ctx[c];  dctx[c] = sum_o do[o] Wo[o][c]
+        const float c = l.ctx[o];
+        for (int oo = wv * 16; oo < wv * 16 + 16; ++oo) GA[kAttOutW + oo * HD + o] = l.vec0[oo] * c;
+        if (wv == 0) {
+            float s = 0.0f;
+            for (int oo = 0; oo < HD; ++oo) s = fmaf(l.vec0[oo], A[kAttOutW + oo * HD + o], s);
+            l.vec1[o] = s;  // dctx
+        }
+    }
+    __syncthreads();
+    if (t < NH * TMAX) {  // softmax backward, 32 lanes per head
+        const int h = t >> 5, j = t & 31;
+        float da = 0.0f;
+        if (j < T) {
+#pragma unroll
+            for (int c = 0; c < DH; ++c) da = fmaf(l.vec1[h * DH + c], l.V[j * HD + h * DH + c], da);
+            if (ms.mode != 0) da = keep_att(ms, w, h, j) ? da * ms.scale : 0.0f;
+        }
+        const float a = l.prob[t];
+        float dot = a * da;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        l.ds[t] = a * (da - dot);
+    }
+    __syncthreads();
+    {
+        // dK[r][o] = ds[h][r] * qs[o];  dq[o] = 0.25 * sum_j ds[h][j] K[j][o]
+        const int h = o >> 4;
+        float dk[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) dk[rr] = r0 + rr < T ? l.ds[h * TMAX + r0 + rr] * l.qs[o] : 0.0f;
+        store_dz(l, dk, true);
+        if (wv == 0) {
+            float s = 0.0f;
+            for (int j = 0; j < T; ++j) s = fmaf(l.ds[h * TMAX + j], l.K[j * HD + o], s);
+            s *= 0.25f;
+            l.vec0[o] = s;  // dq (all reads of the old vec0 = do finished before the previous barrier)
+            GA[kAttInB + o] = s;
+        }
+    }
+    __syncthreads();
+    {  // query rows of in_proj: dWq[o][k] = dq[o] u_last[k]
+        const float ul = l.u[2][(T - 1) * HD + o];
+        for (int oo = wv * 16; oo < wv * 16 + 16; ++oo) GA[kAttInW + oo * HD + o] = l.vec0[oo] * ul;
+    }
+    wgrad<TMAX>(l.dzT, l.u[2], HD, HD, GA + kAttInW + HD * HD, HD, 0);  // key rows
+    bgrad<TMAX>(l.dzT, GA + kAttInB + HD);
+    float du3[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) du3[rr] = 0.0f;
+    dense8<HD>(l.dz, HD, r0, A + kAttInW + HD * HD, HD, o, du3);       // dK Wk
+    if (wv == (T - 1) / 8) {                                          // + Wq^T dq on the last row
+        float s = 0.0f;
+        for (int oo = 0; oo < HD; ++oo) s = fmaf(l.vec0[oo], A[kAttInW + oo * HD + o], s);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+            if (r0 + rr == T - 1) du3[rr] += s;
+    }
+    __syncthreads();
+    {  // dV[r][o] = probd[h][r] * dctx[o]
+        const int h = o >> 4;
+        float dv[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) dv[rr] = r0 + rr < T ? l.probd[h * TMAX + r0 + rr] * l.vec1[o] : 0.0f;
+        store_dz(l, dv, true);
+    }
+    __syncthreads();
+    wgrad<TMAX>(l.dzT, l.u[2], HD, HD, GA + kAttInW + 2 * HD * HD, HD, 0);  // value rows
+    bgrad<TMAX>(l.dzT, GA + kAttInB + 2 * HD);
+    dense8<HD>(l.dz, HD, r0, A + kAttInW + 2 * HD * HD, HD, o, du3);       // + dV Wv
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) l.dU[(r0 + rr) * HD + o] = du3[rr];
+    __syncthreads();
+    grn_backward<TMAX>(l, l.u[1], l.g[1], P + tft_off_grn(F, 1), G + tft_off_grn(F, 1), 4, sc);
+    grn_backward<TMAX>(l, l.u[0], l.g[0], P + tft_off_grn(F, 0), G + tft_off_grn(F, 0), 4, sc);
+    // ---- input projection: dWp[o][k] = sum_r dU[r][o] x[r][k], dbp
+    {
+        float v[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) v[rr] = l.dU[(r0 + rr) * HD + o];
+        __syncthreads();
+        store_dz(l, v, true);
+        __syncthreads();
+        wgrad<TMAX>(l.dzT, l.x, XS, F, G, F, 0);
+        bgrad<TMAX>(l.dzT, G + tft_off_proj_b(F));
+    }
+}
+
+// ---- flat optimiser: grad = sum_b dP[b], clip_grad_norm_, AdamW ------------------------------------------------
+constexpr int kFlatBlocks = 64;
+
+__global__ __launch_bounds__(256) void flat_grad_kernel(const float* __restrict__ dP, int B, int64_t n, float* __restrict__ grad,
+                                                       double* __restrict__ normsq_part) {
+    __shared__ double red[4];
+    double nsq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float a = 0.0f;
+        for (int b = 0; b < B; ++b) a += dP[(int64_t)b * n + i];  // fixed order: deterministic
+        grad[i] = a;
+        nsq += (double)a * a;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nsq += __shfl_down(nsq, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nsq;
+    __syncthreads();
+    if (threadIdx.x == 0) normsq_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct FlatHyper {
+    float lr, beta1, beta2, eps, weight_decay, max_norm, bias1, bias2_sqrt;
+};
+
+__global__ __launch_bounds__(256) void flat_adamw_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ am,
+                                                        float* __restrict__ av, int64_t n, const double* __restrict__ normsq_part,
+                                                        int nparts, FlatHyper hp, float* __restrict__ gnorm) {
+    double nsq = 0.0;
+    for (int i = 0; i < nparts; ++i) nsq += normsq_part[i];
+    const float total = (float)sqrt(nsq);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm) gnorm[0] = total;
+    float coef = hp.max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
+    coef = coef > 1.0f ? 1.0f : coef;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gr = grad[i] * coef;
+        float p = param[i] * (1.0f - hp.lr * hp.weight_decay);
+        const float mm = am[i] + (gr - am[i]) * (1.0f - hp.beta1);
+        const float vv = av[i] * hp.beta2 + (1.0f - hp.beta2) * gr * gr;
+        am[i] = mm;
+        av[i] = vv;
+        p -= (hp.lr / hp.bias1) * (mm / (sqrtf(vv) / hp.bias2_sqrt + hp.eps));
+        param[i] = p;
+    }
+}
+
+TftMasks make_masks(int mode, const uint8_t* g0, const uint8_t* g1, const uint8_t* at, const uint8_t* g2, uint64_t seed, float p_drop) {
+    TftMasks ms;
+    ms.g[0] = g0;
+    ms.g[1] = g1;
+    ms.g[2] = g2;
+    ms.at = at;
+    ms.seed = seed;
+    ms.mode = mode;
+    ms.keep_prob = 1.0f - p_drop;
+    ms.scale = (float)(1.0 / (1.0 - (double)p_drop));
+    return ms;
+}
+
+template <typename K>
+int set_lds(K kernel, const char* what) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(kLdsFloats * sizeof(float)));
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    return MCMC_OK;
+}
+
+}  // namespace
+
+int tft_params(int F) { return tft_param_count(F); }
+int tft_flat_blocks() { return kFlatBlocks; }
+
+int launch_tft_transpose(const float* P, float* PT, int F, hipStream_t s) {
+    hipLaunchKernelGGL(tft_transpose_kernel, dim3(64), dim3(256), 0, s, P, PT, F);
+    return check_launch("tft_transpose");
+}
+
+int launch_tft_forward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
+                       const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop, float* pred,
+                       hipStream_t s) {
+    const size_t lds = kLdsFloats * sizeof(float);
+    const TftMasks ms = make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop);
+    if (mask_mode == 0) {
+        if (int rc = set_lds(tft_forward_kernel<false>, "tft_forward")) return rc;
+        hipLaunchKernelGGL(tft_forward_kernel<false>, dim3(B), dim3(NT), lds, s, X, n_rows, start, T, F, P, PT, ms, pred);
+    } else {
+        if (int rc = set_lds(tft_forward_kernel<true>, "tft_forward")) return rc;
+        hipLaunchKernelGGL(tft_forward_kernel<true>, dim3(B), dim3(NT), lds, s, X, n_rows, start, T, F, P, PT, ms, pred);
+    }
+    return check_launch("tft_forward");
+}
+
+int launch_tft_backward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
+                        const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop,
+                        const float* delta, float* dP, hipStream_t s) {
+    if (int rc = set_lds(tft_backward_kernel, "tft_backward")) return rc;
+    hipLaunchKernelGGL(tft_backward_kernel, dim3(B), dim3(NT), kLdsFloats * sizeof(float), s, X, n_rows, start, T, F, P, PT,
+                       make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop), delta, dP);
+    return check_launch("tft_backward");
+}
+
+int launch_flat_update(float* param, int64_t n, const float* dP, int B, float* grad, float* am, float* av, double* normsq_part, float lr,
+                       float beta1, float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(flat_grad_kernel, dim3(kFlatBlocks), dim3(256), 0, s, dP, B, n, grad, normsq_part);
+    FlatHyper hp;
+    hp.lr = lr;
+    hp.beta1 = beta1;
+    hp.beta2 = beta2;
+    hp.eps = adam_eps;
+    hp.weight_decay = weight_decay;
+    hp.max_norm = max_norm;
+    hp.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
+    hp.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(flat_adamw_kernel, dim3(64), dim3(256), 0, s, param, grad, am, av, n, normsq_part, kFlatBlocks, hp, gnorm);
+    return check_launch("flat_update");
+}
+
+}  // namespace mcmc

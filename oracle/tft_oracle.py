@@ -144,3 +144,33 @@ class TFTTrainOracle:
         total = torch.nn.utils.clip_grad_norm_([self.flat], max_norm)
         self.opt.step()
         return loss.detach(), grad, total.detach(), pred.detach()
+
+
+def philox_masks(seed: int, keys: Sequence[int], T: int, p_drop: float = P_DROP):
+    """The device's Philox dropout decisions as reference-shaped keep-masks for windows keyed ``keys``.
+
+    Stream 'MASK' (mcmc_amd/csrc/philox.hpp:philox_mask_uniform), counter (elem>>2, key, 'MASK', row),
+    component elem&3; elem = grn_index*64 + feature for the three GRNs (feature 0, temporal 1, final 2),
+    192 + head*32 + key_position for the attention row of the last query.  Entries the device never
+    draws (attention rows of other queries) are 1."""
+    from .bnn_oracle import _u01, philox4x32_10
+    B = len(keys)
+
+    def uniform(key, row, elem):
+        row, elem = np.broadcast_arrays(np.asarray(row, dtype=np.uint32), np.asarray(elem, dtype=np.uint32))
+        ctr = np.stack([elem >> np.uint32(2), np.full_like(elem, key), np.full_like(elem, 0x4D41534B), row], axis=-1)
+        k = np.stack([np.full_like(elem, seed & 0xFFFFFFFF), np.full_like(elem, (seed >> 32) & 0xFFFFFFFF)], axis=-1)
+        x = philox4x32_10(ctr, k)
+        return _u01(np.take_along_axis(x, (elem & np.uint32(3)).astype(np.int64)[..., None], axis=-1)[..., 0])
+
+    keep = np.float32(1.0 - p_drop)
+    g = [np.ones((B, T, HIDDEN), dtype=np.uint8) for _ in range(3)]
+    at = np.ones((B * HEADS, T, T), dtype=np.uint8)
+    rows = np.arange(T)[:, None]
+    feats = np.arange(HIDDEN)[None, :]
+    for b, key in enumerate(keys):
+        for which in range(3):
+            g[which][b] = (uniform(key, rows, which * HIDDEN + feats) < keep).astype(np.uint8)
+        for h in range(HEADS):
+            at[b * HEADS + h, T - 1, :] = (uniform(key, T - 1, 3 * HIDDEN + h * 32 + np.arange(T)) < keep).astype(np.uint8)
+    return [torch.from_numpy(g[0]), torch.from_numpy(g[1]), torch.from_numpy(at), torch.from_numpy(g[2])]

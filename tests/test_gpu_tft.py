@@ -1,0 +1,147 @@
+"""GPU parity of the TFT leg against oracle/tft_oracle.py and the reference's own vectors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tft_oracle as tft
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _key_bias(F):
+    off = 0
+    for n, s in tft.param_spec(F):
+        if n == "attention.in_proj_bias":
+            return slice(off + 64, off + 128)
+        off += int(np.prod(s))
+
+
+def _engine(flat, F, T=30, **kw):
+    from mcmc_amd.temporal_fusion import TFTEngine
+    return TFTEngine(torch.as_tensor(flat).to(DEV), F, T, **kw)
+
+
+def _windows(xb):
+    """[B,T,F] batch -> (X [B*T,F], start [B]) on the device."""
+    B, T, F = xb.shape
+    return xb.reshape(B * T, F).contiguous().to(DEV), (torch.arange(B, dtype=torch.int32) * T).to(DEV)
+
+
+def test_tft_eval_forward_and_predict_match_reference(golden):
+    z = golden("tft_fwd.npz")
+    F = z["X"].shape[1]
+    te = _engine(z["flat"], F)
+    X, start = _windows(torch.from_numpy(z["raw_batch"]))
+    got = te.forward(X, start).cpu().numpy()
+    np.testing.assert_allclose(got, z["raw_out"][:, -1, 0], rtol=0, atol=1e-5)
+    # the whole predict(): 336 windows in one launch + the reference's padding
+    from mcmc_amd.temporal_fusion import TFTModel
+    m = TFTModel(num_features=F, device=DEV)
+    m.model.load_flat(torch.from_numpy(z["flat"]).to(DEV))
+    pred = m.predict(torch.from_numpy(z["X"]))
+    assert pred.shape == (365,) and pred.dtype == np.float32 and np.all(pred[:29] == pred[29])
+    np.testing.assert_allclose(pred, z["predict"], rtol=0, atol=1e-5)
+    with pytest.raises(ValueError):
+        m.predict(torch.from_numpy(z["X"])[:, :5])
+
+
+@pytest.mark.parametrize("step", [0, 1])
+def test_tft_train_forward_loss_and_gradient_match_oracle(golden, step):
+    """Reference's recorded batch + dropout masks: prediction, loss, every parameter gradient, clip norm."""
+    z = golden("tft_train.npz")
+    F = z["X"].shape[1]
+    xb, yb = torch.from_numpy(z[f"xb_{step}"]), torch.from_numpy(z[f"yb_{step}"])
+    masks = [torch.from_numpy(z[f"mask{j}_{step}"]) for j in range(4)]
+    o = tft.TFTTrainOracle(torch.from_numpy(z["flat0"]), F)
+    loss, grad, total, pred = o.step(xb, yb, masks, lr=1e-3, beta1=0.9)
+    te = _engine(z["flat0"], F)
+    X, start = _windows(xb)
+    got_loss = te.step(X, start, yb.to(DEV), 1e-3, 0.9, masks=masks).cpu()
+    np.testing.assert_allclose(te.pred[:xb.shape[0]].cpu().numpy(), pred.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got_loss.item(), loss.item(), rtol=2e-5)
+    g = te.grad.cpu().numpy()
+    ref = grad.numpy()
+    off = 0
+    for name, shape in tft.param_spec(F):
+        k = int(np.prod(shape))
+        a, b = g[off:off + k], ref[off:off + k]
+        if name == "attention.in_proj_bias":  # key-bias gradient is exactly zero in exact arithmetic: noise on both sides
+            a, b = np.concatenate([a[:64], a[128:]]), np.concatenate([b[:64], b[128:]])
+            assert np.abs(g[off + 64:off + 128]).max() <= 1e-6
+        scale = max(np.abs(b).max(), 1e-6)
+        assert np.abs(a - b).max() <= 3e-5 * scale + 1e-7, (name, np.abs(a - b).max(), scale)
+        off += k
+    np.testing.assert_allclose(te.gnorm.item(), total.item(), rtol=3e-5)
+
+
+def test_tft_replays_reference_trajectory(golden):
+    z = golden("tft_train.npz")
+    F = z["X"].shape[1]
+    te = _engine(z["flat0"], F)
+    for i in range(int(z["n_steps"])):
+        xb, yb = torch.from_numpy(z[f"xb_{i}"]), torch.from_numpy(z[f"yb_{i}"])
+        masks = [torch.from_numpy(z[f"mask{j}_{i}"]) for j in range(4)]
+        X, start = _windows(xb)
+        loss = te.step(X, start, yb.to(DEV), float(z["lr"][i]), float(z["beta1"][i]), masks=masks).cpu()
+        np.testing.assert_allclose(loss.item(), z["loss"][i], rtol=5e-5)
+    d = np.abs(te.P.cpu().numpy() - z["flat1"])
+    kb = _key_bias(F)
+    rest = np.ones(d.size, dtype=bool)
+    rest[kb] = False
+    lr_sum = float(z["lr"].sum())
+    # Adam's sign-like update: elements whose gradient is ~adam_eps may differ by a part of lr; all others tightly
+    assert d[rest].max() <= 2.0 * lr_sum and np.quantile(d[rest], 0.999) <= 3e-6, (d[rest].max(), np.quantile(d[rest], 0.999))
+    assert d[kb].max() <= 2.02 * lr_sum
+
+
+def test_tft_philox_dropout_matches_oracle_masks(golden):
+    z = golden("tft_fwd.npz")
+    F = z["X"].shape[1]
+    te = _engine(z["flat"], F)
+    X = torch.from_numpy(z["X"]).to(DEV)
+    keys = [3, 100, 200, 335]
+    start = torch.tensor(keys, dtype=torch.int32, device=DEV)
+    seed = 0xABCDEF0123456789
+    got = te.forward(X, start, seed=seed).cpu().numpy()
+    masks = tft.philox_masks(seed, keys, 30)
+    xb = torch.stack([torch.from_numpy(z["X"][k:k + 30]) for k in keys])
+    with torch.no_grad():
+        want = tft.forward(xb, tft.unflatten(torch.from_numpy(z["flat"]), F), masks)[:, -1, 0].numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+    evalp = te.forward(X, start).cpu().numpy()
+    assert np.abs(evalp - got).max() > 1e-3      # dropout really was live
+
+
+def test_tft_model_trains_and_predicts_end_to_end(golden):
+    from mcmc_amd.temporal_fusion import TFTModel
+    z = golden("predict_cfg1.npz")
+    X, y = torch.from_numpy(z["X"]), torch.from_numpy(z["y"])
+    torch.manual_seed(4)
+    m = TFTModel(num_features=X.shape[1], seq_length=30, batch_size=32, device=DEV, seed=9)
+    before = m.predict(X)
+    m.train(X.refine_names("time", "features"), y.refine_names("time"), epochs=25)
+    after = m.predict(X)
+    mse0 = float(((before[29:] - y.numpy()[29:]) ** 2).mean())
+    mse1 = float(((after[29:] - y.numpy()[29:]) ** 2).mean())
+    assert m.epochs_trained == 25 and mse1 < 0.5 * mse0 and mse1 < 0.6, (mse0, mse1)
+    Xs, ys = m.create_sequences(X.refine_names("time", "features"), y.refine_names("time"))
+    assert Xs.names == ("batch", "time", "features") and tuple(Xs.shape) == (336, 30, X.shape[1]) and ys.names == ("batch",)
+    assert torch.equal(Xs.rename(None)[7], X[7:37]) and ys.rename(None)[7] == y[36]
+
+
+def test_tft_capi_rejects_bad_arguments():
+    from mcmc_amd.engine import Engine
+    eng = Engine(torch.device(DEV))
+    lib, h = eng.lib, eng.ctx.handle
+    buf = torch.zeros(1 << 18, device=DEV)
+    p, z = C.c_void_p(buf.data_ptr()), C.c_void_p(0)
+    assert lib.mcmc_tft_forward(h, p, 4096, p, 4, 33, 11, p, p, 0, z, z, z, z, 0, 0.1, p, z) == -1     # seq_len > 32
+    assert lib.mcmc_tft_forward(h, p, 4096, p, 4, 30, 25, p, p, 0, z, z, z, z, 0, 0.1, p, z) == -1     # too many features
+    assert lib.mcmc_tft_forward(h, p, 4096, p, 4, 30, 11, p, p, 1, p, p, z, p, 0, 0.1, p, z) == -1     # host masks incomplete
+    assert lib.mcmc_tft_forward(h, p, 20, p, 4, 30, 11, p, p, 0, z, z, z, z, 0, 0.1, p, z) == -1   # fewer rows than seq_len
+    assert lib.mcmc_tft_transpose(h, p, p, 11, z) == -1                                          # aliased
+    assert lib.mcmc_flat_adamw(h, p, 10, p, 1, p, p, p, p, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0, z, z) == -1
+    assert lib.mcmc_tft_param_count(11) == 67585 and lib.mcmc_tft_param_count(0) == -1

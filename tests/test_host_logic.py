@@ -304,3 +304,22 @@ def test_pipeline_record_schema_and_constant_columns(golden, tmp_path):
     if not torch.cuda.is_available():  # main.py:225-226
         with pytest.raises(RuntimeError):
             pipeline.train_and_evaluate_all(torch.from_numpy(z["features"]), torch.from_numpy(z["temporal"]), y)
+
+
+# ----------------------------------------------------------------------------- TFT host side (row f4)
+def test_tft_module_parameters_follow_the_reference_layout():
+    from oracle import tft_oracle as tft
+    from mcmc_amd import _lib
+    from mcmc_amd.temporal_fusion import TemporalFusionTransformer, TFTModel
+    net = TemporalFusionTransformer(11)
+    assert [(n, tuple(p.shape)) for n, p in net.named_parameters()] == tft.param_spec(11)
+    flat = net.flat_parameters()
+    assert flat.numel() == tft.n_params(11) == _lib.load().mcmc_tft_param_count(11)
+    net2 = TemporalFusionTransformer(11)
+    net2.load_flat(flat)
+    assert all(torch.equal(a, b) for a, b in zip(net.parameters(), net2.parameters()))
+    m = TFTModel(num_features=11, device="cpu")
+    with pytest.raises(RuntimeError):   # no CPU path
+        m.predict(torch.zeros(40, 11))
+    with pytest.raises(ValueError):
+        m.predict(torch.zeros(40, 5))
