@@ -3,9 +3,10 @@
 Mirrors /root/reference/main.py: feature-subset enumeration (:38-57), column selection + concat
 with the calendar features (:71-96), the two StandardScalers (:111-130), train -> predict
 (:148-150,169-170), inverse scaling of the mean and scaling of the std (:174-177), metrics
-(utils.py:30-40) and the JSON record (:183-196, :241-245, :282-283).  Prophet and TFT rows of the
-record are not produced here (out of scope); a record written by this module carries the
-``bayesian`` entry with the reference's keys, plus opt-in ``lower`` / ``upper`` interval bounds.
+(utils.py:30-40) and the JSON record (:183-196, :241-245, :282-283).  The Prophet row of the
+record is not produced here (CPU library, out of scope); a record written by this module carries
+the ``bayesian`` entry with the reference's keys (plus opt-in ``lower`` / ``upper`` interval
+bounds) and, with ``include_tft=True``, the ``tft`` entry (main.py:141-146,158-165,188-191).
 
 Scaling runs as torch ops on whatever device the tensors live on; the arithmetic follows
 sklearn's StandardScaler on float32 input: statistics in float64 (population variance, scale of
@@ -128,9 +129,10 @@ def bayesian_record(mean: torch.Tensor, std: torch.Tensor, y: torch.Tensor, scal
 
 def process_bayesian_task(features: torch.Tensor, temporal: torch.Tensor, target: torch.Tensor, combo: Sequence[int], device,
                           *, epochs: int = 400, train_samples: int = 10, predict_samples: int = 100, interval: Optional[float] = None,
-                          n_models: int = 5, compute_dtype: str = "fp32", seed: Optional[int] = None, log=print):
-    """The Bayesian leg of main.py:process_gpu_task (:60-208) for one feature subset.
-    Returns (combo_name, {"bayesian": record})."""
+                          n_models: int = 5, compute_dtype: str = "fp32", seed: Optional[int] = None, log=print,
+                          include_tft: bool = False, tft_epochs: Optional[int] = None):
+    """The GPU legs of main.py:process_gpu_task (:60-208) for one feature subset: the Bayesian
+    ensemble and, with ``include_tft``, the TFT.  Returns (combo_name, {"bayesian": record[, "tft": record]})."""
     from .bayesian_ensemble import GPUBayesianEnsemble
     device = torch.device(device)
     name = combo_name(combo)
@@ -138,6 +140,16 @@ def process_bayesian_task(features: torch.Tensor, temporal: torch.Tensor, target
     X = select_features(features, temporal, combo).rename(None).to(device)
     y = target.rename(None).to(device)
     Xs, ys, _, sy = scale_inputs(X, y)
+    out = {}
+    if include_tft:  # main.py:141-146,158-165: TFT first, like the reference
+        from .temporal_fusion import TFTModel
+        log(f"Training TFT for {name}")
+        tft_model = TFTModel(num_features=Xs.size("features"), seq_length=30, batch_size=32, device=device, seed=seed)
+        tft_model.train(Xs, ys, epochs=epochs if tft_epochs is None else tft_epochs)
+        tft_preds = sy.inverse_transform(torch.from_numpy(tft_model.predict(Xs)).reshape(-1, 1)).flatten()
+        out["tft"] = {"predictions": tft_preds.tolist(), "metrics": evaluate_predictions(y.cpu(), tft_preds)}
+        log(f"TFT MAPE: {out['tft']['metrics']['mape']:.2f}%")
+    log(f"Training Bayesian for {name}")
     model = GPUBayesianEnsemble(input_dim=Xs.size("features"), n_models=n_models, device=device, batch_size=32,
                                 compute_dtype=compute_dtype, seed=seed)
     model.train(Xs, ys, epochs=epochs, num_samples=train_samples)
@@ -148,7 +160,8 @@ def process_bayesian_task(features: torch.Tensor, temporal: torch.Tensor, target
         mean, std, lo, hi = model.predict_interval(Xs, num_samples=predict_samples, level=interval)
         rec = bayesian_record(mean, std, y, sy, lo, hi)
     log(f"Bayesian MAPE: {rec['metrics']['mape']:.2f}%")
-    return name, {"bayesian": rec}
+    out["bayesian"] = rec
+    return name, out
 
 
 def train_and_evaluate_all(features: torch.Tensor, temporal: torch.Tensor, target: torch.Tensor, feature_dates: Optional[dict] = None,

@@ -145,3 +145,16 @@ def test_tft_capi_rejects_bad_arguments():
     assert lib.mcmc_tft_transpose(h, p, p, 11, z) == -1                                          # aliased
     assert lib.mcmc_flat_adamw(h, p, 10, p, 1, p, p, p, p, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0, z, z) == -1
     assert lib.mcmc_tft_param_count(11) == 67585 and lib.mcmc_tft_param_count(0) == -1
+
+
+def test_pipeline_task_with_tft_leg(golden):
+    """main.py's two GPU legs for one feature subset: record carries 'tft' and 'bayesian' with the reference's keys."""
+    from mcmc_amd import pipeline
+    z = golden("glue_cfg1.npz")
+    feats, temp, target = (torch.from_numpy(z[k]) for k in ("features", "temporal", "target"))
+    torch.manual_seed(2)
+    name, rec = pipeline.process_bayesian_task(feats, temp, target, (0, 1), torch.device(DEV), epochs=30, predict_samples=50, seed=5,
+                                               include_tft=True, log=lambda *_: None)
+    assert name == "0_1" and set(rec) == {"tft", "bayesian"}
+    assert set(rec["tft"]) == {"predictions", "metrics"} and len(rec["tft"]["predictions"]) == 365
+    assert rec["tft"]["metrics"]["mape"] < 15.0 and rec["bayesian"]["metrics"]["mape"] < 15.0, (rec["tft"]["metrics"], rec["bayesian"]["metrics"])
