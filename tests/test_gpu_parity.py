@@ -378,3 +378,30 @@ def test_c_abi_rejects_bad_arguments():
                                                 (__import__("ctypes").c_double * 1)(0.5), 1, _p(Y), _p(Y), _p(Y), _stream()), "x")
     # empty inputs are accepted and do nothing
     assert eng.lib.mcmc_forward(eng.ctx.handle, 0, None, 0, 11, None, 0, None, None, None, 1.0, None, 0, _stream()) == 0
+
+
+@pytest.mark.parametrize("F,B", [(1, 33), (12, 100), (15, 64), (16, 97), (17, 200), (24, 513)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_input_widths_across_the_k_granule(F, B, dtype, tol):
+    """Every input width class: F+1 (bias column) below / at / above the 16-wide bf16 K granule and the
+    kernel's maximum (24), against the oracle's per-pair outputs on the same injected noise."""
+    from mcmc_amd import mc_predict
+    g = torch.Generator().manual_seed(1000 + F)
+    M, S = 2, 3
+    P = orc.n_params(F)
+    X = torch.randn(B, F, generator=g)
+    mu = torch.zeros(M, P)
+    rho = torch.full((M, P), -3.0) + 0.3 * torch.randn(M, P, generator=g)
+    for m in range(M):
+        for (wo, bo, k_in, k_out) in orc.param_offsets(F):
+            mu[m, wo:wo + k_in * k_out] = torch.randn(k_in * k_out, generator=g) * (2.0 / k_in) ** 0.5
+            mu[m, bo:bo + k_out] = 0.1 * torch.randn(k_out, generator=g)
+    eps = torch.randn(M, S, P, generator=g)
+    ref = orc.predict_all(X, mu, rho, eps).numpy()
+    d = _dev()
+    res = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype=dtype, noise="injected", eps=eps.reshape(-1, P).to(d), return_samples=True)
+    got = res.samples.cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert np.max(np.abs(got - ref)) <= tol * scale, (F, B, dtype, float(np.max(np.abs(got - ref))), scale)
+    m_ref, s_ref = orc.reduce_mean_std(torch.from_numpy(ref))
+    _check_stats(res, m_ref.numpy(), s_ref.numpy(), tol if dtype == "fp32" else 5e-2)
