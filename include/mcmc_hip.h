@@ -82,6 +82,13 @@ int mcmc_sample_weights(mcmc_ctx* ctx, const float* mu, const float* rho, int n_
                         int noise_mode, const float* eps, uint64_t seed, int dtype, void* wpack,
                         mcmc_stream_t stream);
 
+/* Same as mcmc_sample_weights with MCMC_NOISE_PHILOX, but the 64-bit key is read from device memory
+ * when the kernel runs: a captured hipGraph can be replayed with a new seed (no counterpart in the
+ * reference, whose randn_like stream advances by itself, bayesian_ensemble.py:43-44). */
+int mcmc_sample_weights_seedptr(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members,
+                                int n_samples, int input_dim, int64_t pair_begin, int pair_count,
+                                const uint64_t* seed_dev, int dtype, void* wpack, mcmc_stream_t stream);
+
 /* Raw Philox noise eps[pair_count, P] fp32 for global pair ids g = g_begin.. (test/inspection:
  * what MCMC_NOISE_PHILOX feeds into mcmc_sample_weights). */
 int mcmc_philox_eps(mcmc_ctx* ctx, uint64_t seed, int64_t g_begin, int pair_count, int input_dim,

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmcmc_hip.so")
 
 DT_F32, DT_BF16 = 0, 1
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MCMCLibraryError(RuntimeError):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "mcmc_wpack_bytes": (_i64, [_i32, _i32]),
     "mcmc_pack_x": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _ptr, _stream]),
     "mcmc_sample_weights": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i32, _i64, _i32, _i32, _ptr, _u64, _i32, _ptr, _stream]),
+    "mcmc_sample_weights_seedptr": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i32, _i64, _i32, _ptr, _i32, _ptr, _stream]),
     "mcmc_philox_eps": (_i32, [_ctx_p, _u64, _i64, _i32, _i32, _ptr, _stream]),
     "mcmc_forward": (_i32, [_ctx_p, _i32, _ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _stream]),
     "mcmc_reduce_update": (_i32, [_ctx_p, _ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _stream]),

@@ -34,7 +34,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 3; }
+int mcmc_abi_version(void) { return 4; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -91,9 +91,9 @@ int mcmc_pack_x(mcmc_ctx* ctx, const float* X, int64_t n_rows, int input_dim, in
     return launch_pack_x(X, n_rows, input_dim, dtype, xpack, (hipStream_t)stream);
 }
 
-int mcmc_sample_weights(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members, int n_samples, int input_dim,
-                        int64_t pair_begin, int pair_count, int noise_mode, const float* eps, uint64_t seed, int dtype,
-                        void* wpack, mcmc_stream_t stream) {
+static int sample_weights_impl(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members, int n_samples, int input_dim,
+                               int64_t pair_begin, int pair_count, int noise_mode, const float* eps, uint64_t seed,
+                               const uint64_t* seed_dev, int dtype, void* wpack, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_dims(input_dim, dtype)) return rc;
     MCMC_REQUIRE(n_members >= 1 && n_samples >= 1, "n_members and n_samples must be >= 1");
@@ -105,8 +105,23 @@ int mcmc_sample_weights(mcmc_ctx* ctx, const float* mu, const float* rho, int n_
     MCMC_REQUIRE(mu && rho && wpack, "mu / rho / wpack is NULL");
     MCMC_REQUIRE(noise_mode != MCMC_NOISE_INJECTED || eps, "MCMC_NOISE_INJECTED needs eps");
     MCMC_REQUIRE(aligned16(wpack), "wpack must be 16-byte aligned");
-    return launch_sample_weights(mu, rho, n_members, n_samples, input_dim, pair_begin, pair_count, noise_mode, eps, seed, dtype,
-                                 wpack, (hipStream_t)stream);
+    return launch_sample_weights(mu, rho, n_members, n_samples, input_dim, pair_begin, pair_count, noise_mode, eps, seed, seed_dev,
+                                 dtype, wpack, (hipStream_t)stream);
+}
+
+int mcmc_sample_weights(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members, int n_samples, int input_dim,
+                        int64_t pair_begin, int pair_count, int noise_mode, const float* eps, uint64_t seed, int dtype,
+                        void* wpack, mcmc_stream_t stream) {
+    return sample_weights_impl(ctx, mu, rho, n_members, n_samples, input_dim, pair_begin, pair_count, noise_mode, eps, seed, nullptr,
+                               dtype, wpack, stream);
+}
+
+int mcmc_sample_weights_seedptr(mcmc_ctx* ctx, const float* mu, const float* rho, int n_members, int n_samples, int input_dim,
+                                int64_t pair_begin, int pair_count, const uint64_t* seed_dev, int dtype, void* wpack,
+                                mcmc_stream_t stream) {
+    MCMC_REQUIRE(seed_dev != nullptr, "seed_dev is NULL");
+    return sample_weights_impl(ctx, mu, rho, n_members, n_samples, input_dim, pair_begin, pair_count, MCMC_NOISE_PHILOX, nullptr, 0,
+                               seed_dev, dtype, wpack, stream);
 }
 
 int mcmc_philox_eps(mcmc_ctx* ctx, uint64_t seed, int64_t g_begin, int pair_count, int input_dim, float* eps, mcmc_stream_t stream) {

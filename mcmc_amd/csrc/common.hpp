@@ -45,7 +45,8 @@ inline int check_launch(const char* what) {
 // kernel launchers (one per .hip file)
 int launch_pack_x(const float* X, int64_t n_rows, int F, int dtype, void* xpack, hipStream_t s);
 int launch_sample_weights(const float* mu, const float* rho, int M, int S, int F, int64_t pair_begin, int pair_count,
-                          int noise_mode, const float* eps, uint64_t seed, int dtype, void* wpack, hipStream_t s);
+                          int noise_mode, const float* eps, uint64_t seed, const uint64_t* seed_dev, int dtype, void* wpack,
+                          hipStream_t s);
 int launch_philox_eps(uint64_t seed, int64_t g_begin, int pair_count, int F, float* eps, hipStream_t s);
 int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count,
                        const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, float keep_scale, float* Y, int64_t ldY,

@@ -2,7 +2,8 @@
 //
 // Restates /root/reference/models/bayesian_ensemble.py:73-92 (3 x {linear, ELU, dropout}, then
 // linear 64->1) on pre-sampled effective weights (sample_weights.hip).  One workgroup = one pair
-// x 128 rows; one wave = 32 rows.  The whole chain stays in registers:
+// x 256 rows (8 waves, two per SIMD so one wave's ELU epilogue hides behind the other's MFMA chain
+// and the staged weights serve twice the rows); one wave = 32 rows.  The whole chain stays in registers:
 //     Z^T[out, batch] = W[out, k] . H^T[k, batch]      (v_mfma_f32_32x32x2_f32, exact fp32 FMAs)
 // leaves feature f(i,h) of each 32-feature tile in accumulator register i, batch row on the
 // lane - exactly the B operand of the next layer's MFMA, whose weights sample_weights.hip stored
@@ -25,8 +26,11 @@ __device__ __forceinline__ void stage(float* lds, const float* __restrict__ src,
     for (int64_t i = threadIdx.x; i < n_floats / 4; i += blockDim.x) d4[i] = s4[i];
 }
 
+constexpr int kWavesF32 = 8;                 // waves per workgroup
+constexpr int kRowsF32 = 32 * kWavesF32;    // rows per workgroup
+
 template <bool MASKED>
-__global__ __launch_bounds__(256, 1) void forward_f32_kernel(const float* __restrict__ xpack, int64_t n_rows, int F,
+__global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const float* __restrict__ xpack, int64_t n_rows, int F,
                                                              const float* __restrict__ wpack, const uint8_t* __restrict__ m0,
                                                              const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
                                                              float keep_scale, float* __restrict__ Y, int64_t ldY) {
@@ -37,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void forward_f32_kernel(const float* __rest
     const float* wp = wpack + (int64_t)c * L.total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)blockIdx.x * 128 + 32 * wave;
+    const int64_t row0 = (int64_t)blockIdx.x * kRowsF32 + 32 * wave;
     const int64_t row = row0 + r;
     const bool active = row0 < rows_pad(n_rows);  // wave-uniform
     const bool real_row = row < n_rows;
@@ -135,11 +139,11 @@ int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* w
     auto kern = masked ? forward_f32_kernel<true> : forward_f32_kernel<false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_f32, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
-    const int64_t row_blocks = (rows_pad(n_rows) + 127) / 128;
+    const int64_t row_blocks = (rows_pad(n_rows) + kRowsF32 - 1) / kRowsF32;
     for (int done = 0; done < pair_count;) {
         const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
         const int64_t mask_pair = n_rows;  // masks advance by n_rows * width per pair
-        hipLaunchKernelGGL(kern, dim3((unsigned)row_blocks, n), dim3(256), lds_bytes, s, xpack, n_rows, F,
+        hipLaunchKernelGGL(kern, dim3((unsigned)row_blocks, n), dim3(64 * kWavesF32), lds_bytes, s, xpack, n_rows, F,
                            wpack + (int64_t)done * L.total, masked ? m0 + (int64_t)done * mask_pair * H1 : nullptr,
                            masked ? m1 + (int64_t)done * mask_pair * H2 : nullptr,
                            masked ? m2 + (int64_t)done * mask_pair * H3 : nullptr, keep_scale, Y + (int64_t)done * ldY, ldY);

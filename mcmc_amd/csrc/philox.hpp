@@ -52,6 +52,18 @@ __device__ inline float philox_normal(uint64_t seed, uint32_t pair, uint32_t idx
     return (comp & 1u) ? r * sinf(theta) : r * cosf(theta);
 }
 
+// The four normals of Philox block `blk` (= parameter indices 4*blk .. 4*blk+3) at once: the same values
+// philox_normal returns for them, for a quarter of the Philox work and half the log / sqrt.
+__device__ inline void philox_normal4(uint64_t seed, uint32_t pair, uint32_t blk, float (&z)[4]) {
+    const u32x4 x = philox4x32_10(u32x4{blk, pair, kTagNoise, 0u}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float r0 = sqrtf(-2.0f * logf(u01(x.x))), t0 = 6.283185307179586f * u01(x.y);
+    const float r1 = sqrtf(-2.0f * logf(u01(x.z))), t1 = 6.283185307179586f * u01(x.w);
+    z[0] = r0 * cosf(t0);
+    z[1] = r0 * sinf(t0);
+    z[2] = r1 * cosf(t1);
+    z[3] = r1 * sinf(t1);
+}
+
 // Uniform in (0,1) for dropout element `elem` of row `row`, global pair id `pair`.
 __device__ inline float philox_mask_uniform(uint64_t seed, uint32_t pair, uint32_t row, uint32_t elem) {
     const u32x4 x = philox4x32_10(u32x4{elem >> 2, pair, kTagMask, row}, (uint32_t)seed, (uint32_t)(seed >> 32));

@@ -20,6 +20,7 @@ struct NoiseSrc {
     const float* rho;  // [M,P]
     const float* eps;  // [M*S,P] or null
     uint64_t seed;
+    const uint64_t* seed_dev;  // when set, the Philox key is read from device memory (graph replay with a new seed)
     int mode;
     int64_t P;
 };
@@ -28,10 +29,30 @@ struct NoiseSrc {
 __device__ __forceinline__ float effective_weight(const NoiseSrc& ns, int m, uint32_t g, int64_t idx) {
     const float mu = ns.mu[(int64_t)m * ns.P + idx];
     if (ns.mode == MCMC_NOISE_NONE) return mu;
-    const float e = ns.mode == MCMC_NOISE_INJECTED ? ns.eps[(int64_t)g * ns.P + idx] : philox_normal(ns.seed, g, (uint32_t)idx);
+    const float e = ns.mode == MCMC_NOISE_INJECTED ? ns.eps[(int64_t)g * ns.P + idx] : philox_normal(ns.seed_dev ? *ns.seed_dev : ns.seed, g, (uint32_t)idx);
     const float sigma = expf(ns.rho[(int64_t)m * ns.P + idx]);
     // two roundings like torch's mul then add (no fma contraction)
     return __fadd_rn(mu, __fmul_rn(e, sigma));
+}
+
+// effective weights of the four consecutive flat parameters idx0 .. idx0+3 (idx0 % 4 == 0: one Philox block)
+__device__ __forceinline__ void effective_weight4(const NoiseSrc& ns, int m, uint32_t g, int64_t idx0, float (&w)[4]) {
+    const float* mu = ns.mu + (int64_t)m * ns.P + idx0;
+    if (ns.mode == MCMC_NOISE_NONE) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = mu[t];
+        return;
+    }
+    float e[4];
+    if (ns.mode == MCMC_NOISE_INJECTED) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e[t] = ns.eps[(int64_t)g * ns.P + idx0 + t];
+    } else {
+        philox_normal4(ns.seed_dev ? *ns.seed_dev : ns.seed, g, (uint32_t)(idx0 >> 2), e);
+    }
+    const float* rho = ns.rho + (int64_t)m * ns.P + idx0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = __fadd_rn(mu[t], __fmul_rn(e[t], expf(rho[t])));
 }
 
 // flat index of the layer-0 A element (out, k): W0 column, the bias column at k == F, or -1 (zero pad)
@@ -56,18 +77,12 @@ __global__ __launch_bounds__(256) void sample_weights_f32_kernel(NoiseSrc ns, in
             const int lane = (int)(e & 63), step = (int)((e >> 6) % ks0), mo = (int)((e >> 6) / ks0);
             idx = l0_flat(F, 32 * mo + (lane & 31), 2 * step + (lane >> 5));
         } else if (e < L.b1) {
-            const int64_t l = e - L.l1;
-            const int lane = (int)(l & 63), step = (int)((l >> 6) & 127), mo = (int)(l >> 13);
-            const int k = 32 * (step >> 4) + acc_feature(step & 15, lane >> 5);
-            idx = flat_w_off(F, 1) + (int64_t)(32 * mo + (lane & 31)) * H1 + k;
+            continue;  // layer-1 weights: quad loop below
         } else if (e < L.l2) {
             const int l = (int)(e - L.b1);
             idx = flat_b_off(F, 1) + 32 * (l >> 5) + acc_feature(l & 15, (l >> 4) & 1);
         } else if (e < L.b2) {
-            const int64_t l = e - L.l2;
-            const int lane = (int)(l & 63), step = (int)((l >> 6) & 63), mo = (int)(l >> 12);
-            const int k = 32 * (step >> 4) + acc_feature(step & 15, lane >> 5);
-            idx = flat_w_off(F, 2) + (int64_t)(32 * mo + (lane & 31)) * H2 + k;
+            continue;  // layer-2 weights: quad loop below
         } else if (e < L.w3) {
             const int l = (int)(e - L.b2);
             idx = flat_b_off(F, 2) + 32 * (l >> 5) + acc_feature(l & 15, (l >> 4) & 1);
@@ -78,6 +93,25 @@ __global__ __launch_bounds__(256) void sample_weights_f32_kernel(NoiseSrc ns, in
             idx = flat_b_off(F, 3);
         }
         out[e] = idx >= 0 ? effective_weight(ns, m, g, idx) : 0.0f;
+    }
+    // Layers 1-2: four consecutive k-steps of one lane are four consecutive k of one weight row
+    // (acc_feature(4a+t, h) = t + 8a + 4h) = one Philox block; the four stores sit 64 floats apart.
+    const int64_t q1 = (L.b1 - L.l1) / 4, q2 = (L.b2 - L.l2) / 4;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < q1 + q2; u += (int64_t)gridDim.x * blockDim.x) {
+        const bool first = u < q1;
+        const int64_t v = first ? u : u - q1;
+        const int lane = (int)(v & 63);
+        const int sq = first ? (int)((v >> 6) & 31) : (int)((v >> 6) & 15);   // step quad: 128 / 64 k-steps per row tile
+        const int mo = first ? (int)(v >> 11) : (int)(v >> 10);
+        const int step = 4 * sq;
+        const int k = 32 * (step >> 4) + acc_feature(step & 15, lane >> 5);
+        const int64_t idx0 = first ? flat_w_off(F, 1) + (int64_t)(32 * mo + (lane & 31)) * H1 + k
+                                   : flat_w_off(F, 2) + (int64_t)(32 * mo + (lane & 31)) * H2 + k;
+        float w[4];
+        effective_weight4(ns, m, g, idx0, w);
+        float* dst = out + (first ? L.l1 : L.l2) + (((int64_t)mo * (first ? 128 : 64) + step) << 6) + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[t << 6] = w[t];
     }
 }
 
@@ -99,6 +133,27 @@ __global__ __launch_bounds__(256) void sample_weights_bf16_kernel(NoiseSrc ns, i
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += (int64_t)gridDim.x * blockDim.x) {
         const int64_t byte = d * 4;
         uint32_t word = 0;
+        if (byte >= L.l1 && byte < L.b1) {
+            // layers 1-2: elements j..j+3 (j = 0 or 4) of a lane's fragment are four consecutive k of one
+            // weight row = one Philox block; the even dword of each 8-byte unit produces both dwords
+            if (d & 1) continue;
+            const int64_t el = byte / 2;
+            int64_t idx0;
+            if (byte < L.l2) {
+                const int64_t l = el - L.l1 / 2;
+                const int j = (int)(l & 7), lane = (int)((l >> 3) & 63), step = (int)((l >> 9) & 15), mo = (int)(l >> 13);
+                idx0 = flat_w_off(F, 1) + (int64_t)(32 * mo + (lane & 31)) * H1 + kperm_bf16(step >> 1, step & 1, lane >> 5, j);
+            } else {
+                const int64_t l = el - L.l2 / 2;
+                const int j = (int)(l & 7), lane = (int)((l >> 3) & 63), step = (int)((l >> 9) & 7), mo = (int)(l >> 12);
+                idx0 = flat_w_off(F, 2) + (int64_t)(32 * mo + (lane & 31)) * H2 + kperm_bf16(step >> 1, step & 1, lane >> 5, j);
+            }
+            float w[4];
+            effective_weight4(ns, m, g, idx0, w);
+            out[d] = bf16_bits(w[0]) | (bf16_bits(w[1]) << 16);
+            out[d + 1] = bf16_bits(w[2]) | (bf16_bits(w[3]) << 16);
+            continue;
+        }
         if (byte < L.b1) {
             // two consecutive bf16 elements j, j+1 of one lane's 8-element fragment
             float v[2];
@@ -200,8 +255,9 @@ int launch_pack_x(const float* X, int64_t n_rows, int F, int dtype, void* xpack,
 }
 
 int launch_sample_weights(const float* mu, const float* rho, int M, int S, int F, int64_t pair_begin, int pair_count,
-                          int noise_mode, const float* eps, uint64_t seed, int dtype, void* wpack, hipStream_t s) {
-    NoiseSrc ns{mu, rho, eps, seed, noise_mode, flat_param_count(F)};
+                          int noise_mode, const float* eps, uint64_t seed, const uint64_t* seed_dev, int dtype, void* wpack,
+                          hipStream_t s) {
+    NoiseSrc ns{mu, rho, eps, seed, seed_dev, noise_mode, flat_param_count(F)};
     // gridDim.y is limited to 65535: walk the pair range in slabs
     for (int done = 0; done < pair_count;) {
         const int n = pair_count - done > 32768 ? 32768 : pair_count - done;

@@ -393,3 +393,87 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
         mean, std, quant = eng.finalize(r1 - r0, part, q_levels)
         mean, std, quant = gather_rows([mean, std, quant], B, group)
     return PredictResult(mean, std, quant, width, samples, part.n)
+
+
+class PredictPlan:
+    """A captured hipGraph of one whole predict for a fixed shape: the launch-bound regime.
+
+    At the reference's own size (365 rows, 5 x 100 pairs) a predict is ~10 launches of a few
+    microseconds each, so the Python / launch overhead is most of the wall time.  The plan allocates
+    every buffer once, captures  pack_x -> sample_weights (Philox key read from device memory) ->
+    forward -> pilot moments -> histogram edges -> reduce -> finalize  into one graph, and a call is
+    three small copies (inputs, seed) + one graph launch.  Single chunk, single rank: all M*S pairs
+    must fit the sample buffer (use mc_predict for the big configurations).
+    Results are views of the plan's static outputs: valid until the next call."""
+
+    def __init__(self, n_rows: int, input_dim: int, n_members: int, num_samples: int, *, device, dtype="fp32",
+                 q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0):
+        self.eng = Engine(torch.device(device))
+        dev = self.eng.device
+        self.B, self.F, self.M, self.S = n_rows, input_dim, n_members, int(num_samples)
+        self.N = self.M * self.S
+        self.P = param_count(input_dim)
+        self.dt = resolve_dtype(dtype)
+        self.q_levels, self.nbins, self.range_sigmas = tuple(q_levels), nbins, range_sigmas
+        nq = len(self.q_levels)
+        if nq and self.N > 65535:
+            raise ValueError(f"quantile histograms count in uint16: M*S = {self.N} exceeds 65,535")
+        self.ldY = (n_rows + 63) // 64 * 64
+        need = self.N * (self.ldY * 4 + self.eng.wpack_bytes(input_dim, self.dt))
+        if need > (8 << 30):
+            raise ValueError(f"a PredictPlan holds all {self.N} pairs in one chunk ({need >> 20} MiB); use mc_predict")
+        with torch.cuda.device(dev):
+            self.X = torch.zeros(n_rows, input_dim, dtype=torch.float32, device=dev)
+            self.mu = torch.zeros(n_members, self.P, dtype=torch.float32, device=dev)
+            self.rho = torch.zeros(n_members, self.P, dtype=torch.float32, device=dev)
+            self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+            self.Y = torch.empty(self.N, self.ldY, dtype=torch.float32, device=dev)
+            self.wpack = torch.empty(self.N * self.eng.wpack_bytes(input_dim, self.dt), dtype=torch.uint8, device=dev)
+            self.state = self.eng.new_state(n_rows, nbins if nq else 0)
+            self.pilot = self.eng.new_state(n_rows)
+            self.graph = None
+            self.out = None
+
+    def _body(self):
+        eng, st, pilot = self.eng, self.state, self.pilot
+        xpack = eng.pack_x(self.X, self.dt)
+        _lib.check(eng.lib.mcmc_sample_weights_seedptr(eng.ctx.handle, _p(self.mu), _p(self.rho), self.M, self.S, self.F, 0, self.N,
+                                                       _p(self.seed), self.dt, _p(self.wpack), _stream()), "mcmc_sample_weights_seedptr")
+        eng.forward(self.dt, xpack, self.B, self.F, self.wpack, self.N, self.Y, self.ldY)
+        for t in (st.sum, st.sumsq, pilot.sum, pilot.sumsq):
+            t.zero_()
+        st.n = pilot.n = 0
+        if self.q_levels:
+            st.hist.zero_()
+            eng.reduce_update(self.Y, self.ldY, self.N, self.B, pilot)
+            eng.set_edges(self.B, pilot.n, pilot.sum, pilot.sumsq, st, self.range_sigmas)
+        eng.reduce_update(self.Y, self.ldY, self.N, self.B, st)
+        mean, std, quant = eng.finalize(self.B, st, self.q_levels)
+        width = (1.0 / st.inv_w) if self.q_levels else None
+        return PredictResult(mean, std, quant, width, None, st.n)
+
+    def capture(self):
+        with torch.cuda.device(self.eng.device):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up outside the capture (lazy module loads, function attributes)
+                self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+        return self
+
+    def __call__(self, X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, seed: int) -> PredictResult:
+        if tuple(X.shape) != (self.B, self.F) or tuple(mu.shape) != (self.M, self.P) or tuple(rho.shape) != (self.M, self.P):
+            raise ValueError(f"plan is for X [{self.B},{self.F}], mu/rho [{self.M},{self.P}]")
+        if self.graph is None:
+            self.capture()
+        self.X.copy_(X.rename(None), non_blocking=True)
+        self.mu.copy_(mu, non_blocking=True)
+        self.rho.copy_(rho, non_blocking=True)
+        s = seed & 0xFFFFFFFFFFFFFFFF
+        self.seed.fill_(s - (1 << 64) if s >= (1 << 63) else s)  # same 64 bits, as a signed value
+        self.graph.replay()
+        return self.out

@@ -405,3 +405,28 @@ def test_input_widths_across_the_k_granule(F, B, dtype, tol):
     assert np.max(np.abs(got - ref)) <= tol * scale, (F, B, dtype, float(np.max(np.abs(got - ref))), scale)
     m_ref, s_ref = orc.reduce_mean_std(torch.from_numpy(ref))
     _check_stats(res, m_ref.numpy(), s_ref.numpy(), tol if dtype == "fp32" else 5e-2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_predict_plan_graph_replay_equals_eager(golden, dtype):
+    """The captured hipGraph of a whole predict gives what mc_predict gives for the same seed, replay after replay."""
+    from mcmc_amd import mc_predict
+    from mcmc_amd.engine import PredictPlan
+    g = golden("predict_cfg1.npz")
+    d = _dev()
+    X = torch.from_numpy(g["X"]).to(d)
+    mu, rho = torch.from_numpy(g["mu"]).to(d), torch.from_numpy(g["rho"]).to(d)
+    M, S = mu.shape[0], 40
+    plan = PredictPlan(X.shape[0], X.shape[1], M, S, device=d, dtype=dtype, q_levels=Q)
+    for seed in (7, 0xFEDCBA9876543210, 7):
+        got = plan(X, mu, rho, seed)
+        want = mc_predict(X, mu, rho, S, dtype=dtype, seed=seed, q_levels=Q)
+        assert got.n_samples == want.n_samples == M * S
+        assert torch.equal(got.mean, want.mean) and torch.equal(got.std, want.std) and torch.equal(got.quantiles, want.quantiles)
+    other = plan(X, mu, rho, 8).mean.clone()
+    assert not torch.equal(other, plan(X, mu, rho, 7).mean)
+    # new inputs through the same graph
+    X2 = X.flip(0).contiguous()
+    assert torch.equal(plan(X2, mu, rho, 3).mean, mc_predict(X2, mu, rho, S, dtype=dtype, seed=3, q_levels=Q).mean)
+    with pytest.raises(ValueError):
+        plan(X[:100], mu, rho, 1)

@@ -20,3 +20,18 @@ for dtype in ("fp32", "bf16"):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print(f"config2 {dtype} quantiles={bool(q)}: {dt * 1e3:.3f} ms per predict  {365 * 500 / dt:.3e} units/s")
+
+from mcmc_amd.engine import PredictPlan
+for dtype in ("fp32", "bf16"):
+    for q in ((), (0.025, 0.975)):
+        plan = PredictPlan(X.shape[0], X.shape[1], mu.shape[0], 100, device=d, dtype=dtype, q_levels=q)
+        for _ in range(3):
+            plan(X, mu, rho, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 200
+        for i in range(n):
+            r = plan(X, mu, rho, i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"config2 {dtype} quantiles={bool(q)} hipGraph plan: {dt * 1e3:.3f} ms per predict  {365 * 500 / dt:.3e} units/s")

@@ -37,6 +37,14 @@ __global__ void rate_kernel(float* out, unsigned long long* cyc, int iters) {
             if (KIND == 21) asm volatile("v_max_f32_e32 %0, %1, %0" : "+v"(x[i]) : "v"(x[(i + 5) & 15]));
             if (KIND == 22) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(x[i]) : "v"(c));
             if (KIND == 23) asm volatile("v_mov_b32_e32 %0, %1" : "+v"(x[i]) : "v"(c));
+            if (KIND == 24) asm volatile("v_exp_legacy_f32 %0, %0" : "+v"(x[i]));
+            if (KIND == 25) asm volatile("v_maximum3_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(c));
+            if (KIND == 26) asm volatile("v_max_i32_e32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+            if (KIND == 27) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(c));
+            if (KIND == 28) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x[i]) : "v"(c));
+            if (KIND == 29) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(x[i]));
+            if (KIND == 30) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(c));
+            if (KIND == 31) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %1" : "+v"(x[i]) : "v"(c));
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -81,6 +89,14 @@ void run(const char* name, int waves_per_simd) {
 
 int main() {
     for (int w : {4}) {
+        run<24>("v_exp_legacy_f32", w);
+        run<25>("v_maximum3_f32", w);
+        run<26>("v_max_i32", w);
+        run<27>("v_max3_f32", w);
+        run<28>("v_ldexp_f32", w);
+        run<29>("v_rcp_f32", w);
+        run<30>("v_perm_b32", w);
+        run<31>("v_pk_maximum3_f16", w);
         run<0>("v_exp_f32 clamp", w);
         run<11>("v_exp_f32 e32", w);
         run<1>("v_fma_f32", w);
