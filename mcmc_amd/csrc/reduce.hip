@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
 
     float lo[4] = {0, 0, 0, 0}, inv_w[4] = {0, 0, 0, 0};
     if (HIST) {
-        for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) lh[i] = 0u;
+        for (int i = threadIdx.x; i < kRows * words / 4; i += kRows * kWavesR) reinterpret_cast<uint4*>(lh)[i] = uint4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (row0 + j < n_rows) {
@@ -178,21 +178,23 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
     using yes = std::true_type;
     using no = std::false_type;
     const bool full_tile = row_base + kRows <= n_rows;  // block-uniform: no per-row bounds checks
-    int c = slot;
     if (loadable) {
-        for (; c + (kUnroll4 - 1) * kSlots < n_pairs; c += kUnroll4 * kSlots) {
-            f32x4 q[kUnroll4];
+        if (full_tile) {
+            int c = slot;
+            for (; c + (kUnroll4 - 1) * kSlots < n_pairs; c += kUnroll4 * kSlots) {
+                f32x4 q[kUnroll4];
 #pragma unroll
-            for (int u = 0; u < kUnroll4; ++u) q[u] = __builtin_nontemporal_load(yp + (int64_t)(c + u * kSlots) * ld4);
-            if (full_tile) {
+                for (int u = 0; u < kUnroll4; ++u) q[u] = __builtin_nontemporal_load(yp + (int64_t)(c + u * kSlots) * ld4);
 #pragma unroll
                 for (int u = 0; u < kUnroll4; ++u) consume(q[u], no{});
-            } else {
-#pragma unroll
-                for (int u = 0; u < kUnroll4; ++u) consume(q[u], yes{});
             }
+            for (; c < n_pairs; c += kSlots) consume(__builtin_nontemporal_load(yp + (int64_t)c * ld4), no{});
+        } else {
+            // the one ragged tile of the launch: per-row bounds checks, no unrolling (keeps the register
+            // count of the kernel that of the full-tile loop)
+#pragma unroll 1
+            for (int c = slot; c < n_pairs; c += kSlots) consume(__builtin_nontemporal_load(yp + (int64_t)c * ld4), yes{});
         }
-        for (; c < n_pairs; c += kSlots) consume(__builtin_nontemporal_load(yp + (int64_t)c * ld4), yes{});
     }
     // the 4 pair-slots of a wave sit 16 lanes apart: fold them, then the waves through LDS
 #pragma unroll
@@ -221,11 +223,41 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
         sumsq[row_base + lane] += b;
     }
     if (HIST) {
-        for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) {
-            const int rl = i / words, w = i & (words - 1);
-            if (row_base + rl < n_rows) {
-                const uint32_t add = lh[rl * words + ((w + 2 * (rl >> 2)) & (words - 1))];
-                if (add) hist[(row_base + rl) * words + w] += add;
+        if (full_tile) {
+            // the tile's 64 rows are one contiguous [64 x words] block of the global histogram: 16-byte
+            // read-modify-write, four independent loads in flight per thread (the state pass is pure
+            // latency otherwise: every workgroup ends with it)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4* hg = reinterpret_cast<u32x4*>(hist + row_base * words);
+            const int n4 = kRows * words / 4;
+            for (int base = threadIdx.x; base < n4; base += 4 * kRows * kWavesR) {
+                u32x4 g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i4 = base + u * kRows * kWavesR;
+                    if (i4 < n4) g[u] = __builtin_nontemporal_load(hg + i4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i4 = base + u * kRows * kWavesR;
+                    if (i4 < n4) {
+                        const int rl = (4 * i4) / words, w = (4 * i4) & (words - 1), rot = 2 * (rl >> 2);
+                        const uint32_t* lr = lh + rl * words;
+                        g[u].x += lr[(w + rot) & (words - 1)];
+                        g[u].y += lr[(w + 1 + rot) & (words - 1)];
+                        g[u].z += lr[(w + 2 + rot) & (words - 1)];
+                        g[u].w += lr[(w + 3 + rot) & (words - 1)];
+                        __builtin_nontemporal_store(g[u], hg + i4);
+                    }
+                }
+            }
+        } else {
+            for (int i = threadIdx.x; i < kRows * words; i += kRows * kWavesR) {
+                const int rl = i / words, w = i & (words - 1);
+                if (row_base + rl < n_rows) {
+                    const uint32_t add = lh[rl * words + ((w + 2 * (rl >> 2)) & (words - 1))];
+                    if (add) hist[(row_base + rl) * words + w] += add;
+                }
             }
         }
     }
