@@ -193,6 +193,21 @@ int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_
                       float weight_decay, float max_norm, int64_t step, float* gnorm,
                       mcmc_stream_t stream);
 
+/* The two halves of mcmc_train_update for the data-parallel step (BASELINE config 5, SURVEY.md 8e:
+ * rows of each member's batch sharded over ranks): mcmc_train_grad forms this rank's (gmu, grho)
+ * from its dW; the caller sum-all-reduces them (RCCL; the reference has no counterpart - it is
+ * single-process, loss.backward() at bayesian_ensemble.py:178 sees the whole batch);
+ * mcmc_train_apply recomputes the norm of the combined gradient, then clips and applies AdamW
+ * exactly as mcmc_train_update does (:179-180). */
+int mcmc_train_grad(mcmc_ctx* ctx, int n_members, int n_samples, int input_dim, const float* eps,
+                    const float* sigma, const float* dW, float* gmu, float* grho,
+                    double* norm_scratch, mcmc_stream_t stream);
+int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members,
+                     int input_dim, const float* gmu, const float* grho, float* adam_m,
+                     float* adam_v, double* norm_scratch, const uint8_t* active, float lr,
+                     float beta1, float beta2, float adam_eps, float weight_decay, float max_norm,
+                     int64_t step, float* gnorm, mcmc_stream_t stream);
+
 /* ---- next row: the Temporal Fusion Transformer leg ------------------------ */
 /* models/temporal_fusion.py.  Parameters are ONE flat fp32 vector in the reference module's
  * named_parameters() order (input_projection, feature_grn, temporal_grn, attention, final_grn,

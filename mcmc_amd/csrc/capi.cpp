@@ -34,7 +34,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 4; }
+int mcmc_abi_version(void) { return 5; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -311,6 +311,26 @@ int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_
     MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
     return launch_train_update(mu, rho, sigma, n_members, n_samples, input_dim, eps, dW, gmu, grho, adam_m, adam_v, norm_scratch, active,
                                lr, beta1, beta2, adam_eps, weight_decay, max_norm, step, gnorm, (hipStream_t)stream);
+}
+
+int mcmc_train_grad(mcmc_ctx* ctx, int n_members, int n_samples, int input_dim, const float* eps, const float* sigma, const float* dW,
+                    float* gmu, float* grho, double* norm_scratch, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, 1)) return rc;
+    MCMC_REQUIRE(eps && sigma && dW && gmu && grho && norm_scratch, "NULL pointer");
+    return launch_train_grad(n_members, n_samples, input_dim, eps, sigma, dW, gmu, grho, norm_scratch, (hipStream_t)stream);
+}
+
+int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members, int input_dim, const float* gmu,
+                     const float* grho, float* adam_m, float* adam_v, double* norm_scratch, const uint8_t* active, float lr, float beta1,
+                     float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, 1, input_dim, 1)) return rc;
+    MCMC_REQUIRE(mu && rho && sigma && gmu && grho && adam_m && adam_v && norm_scratch, "NULL pointer");
+    MCMC_REQUIRE(step >= 1, "step is 1-based");
+    MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
+    return launch_train_apply(mu, rho, sigma, n_members, input_dim, gmu, grho, adam_m, adam_v, norm_scratch, true, active, lr, beta1,
+                              beta2, adam_eps, weight_decay, max_norm, step, gnorm, (hipStream_t)stream);
 }
 
 // ---- TFT (row f4) ---------------------------------------------------------------------------------------

@@ -474,6 +474,24 @@ __global__ __launch_bounds__(256) void train_grad_kernel(const float* __restrict
     if (threadIdx.x == 0) normsq_part[(int64_t)m * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// T5b: per-block squared norms of finished (mu, rho) gradients - the data-parallel step recomputes them
+// after the gradient all-reduce (same grid and summation order as train_grad_kernel)
+__global__ __launch_bounds__(256) void train_gradnorm_kernel(const float* __restrict__ gmu, const float* __restrict__ grho, int64_t P,
+                                                            double* __restrict__ normsq_part) {
+    __shared__ double red[4];
+    const int m = blockIdx.y;
+    double nsq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = gmu[m * P + i], b = grho[m * P + i];
+        nsq += (double)a * a + (double)b * b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nsq += __shfl_down(nsq, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nsq;
+    __syncthreads();
+    if (threadIdx.x == 0) normsq_part[(int64_t)m * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 struct AdamHyper {
     float lr, beta1, beta2, eps, weight_decay, max_norm;
     float bias1, bias2_sqrt;  // 1 - beta1^t, sqrt(1 - beta2^t)
@@ -570,11 +588,18 @@ int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, co
     return check_launch("train_backward");
 }
 
-int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F, const float* eps, const float* dW, float* gmu,
-                        float* grho, float* am, float* av, double* normsq_part, const uint8_t* active, float lr, float beta1,
-                        float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s) {
+int launch_train_grad(int M, int S, int F, const float* eps, const float* sigma, const float* dW, float* gmu, float* grho,
+                      double* normsq_part, hipStream_t s) {
     const int64_t P = flat_param_count(F);
     hipLaunchKernelGGL(train_grad_kernel, dim3(kGradBlocks, M), dim3(256), 0, s, dW, eps, sigma, S, P, gmu, grho, normsq_part);
+    return check_launch("train_grad");
+}
+
+int launch_train_apply(float* mu, float* rho, float* sigma, int M, int F, const float* gmu, const float* grho, float* am, float* av,
+                       double* normsq_part, bool recompute_norm, const uint8_t* active, float lr, float beta1, float beta2,
+                       float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s) {
+    const int64_t P = flat_param_count(F);
+    if (recompute_norm) hipLaunchKernelGGL(train_gradnorm_kernel, dim3(kGradBlocks, M), dim3(256), 0, s, gmu, grho, P, normsq_part);
     AdamHyper hp;
     hp.lr = lr;
     hp.beta1 = beta1;
@@ -586,7 +611,15 @@ int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F
     hp.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(train_adamw_kernel, dim3(64, M), dim3(256), 0, s, mu, rho, sigma, gmu, grho, am, av, P, normsq_part, kGradBlocks,
                        active, hp, gnorm);
-    return check_launch("train_update");
+    return check_launch("train_apply");
+}
+
+int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F, const float* eps, const float* dW, float* gmu,
+                        float* grho, float* am, float* av, double* normsq_part, const uint8_t* active, float lr, float beta1,
+                        float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s) {
+    if (int rc = launch_train_grad(M, S, F, eps, sigma, dW, gmu, grho, normsq_part, s)) return rc;
+    return launch_train_apply(mu, rho, sigma, M, F, gmu, grho, am, av, normsq_part, false, active, lr, beta1, beta2, adam_eps,
+                              weight_decay, max_norm, step, gnorm, s);
 }
 
 int train_grad_blocks() { return kGradBlocks; }

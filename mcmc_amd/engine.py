@@ -94,6 +94,25 @@ class ReduceState:
     nbins: int = 0
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks of ``group``.  RCCL ('nccl') reduces device tensors directly over xGMI.
+    Under gloo (CPU tests; rehearsals where several ranks share one GPU) a device tensor goes through host
+    memory here, explicitly: gloo's own staging of large device tensors hung when two ranks shared a card."""
+    import torch.distributed as dist
+    if _via_host(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def combine_partials(state: ReduceState, group=None) -> ReduceState:
     """Sum-combine the partials of all ranks: fp64 moments and the histogram
     (uint16 pairs viewed as int32: no carry crosses a half while total counts stay <= 65,535).
@@ -103,14 +122,14 @@ def combine_partials(state: ReduceState, group=None) -> ReduceState:
         return state
     moments = torch.stack([state.sum, state.sumsq])
     count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
-    dist.all_reduce(moments, group=group)
-    dist.all_reduce(count, group=group)
+    all_reduce_sum(moments, group)
+    all_reduce_sum(count, group)
     state.sum, state.sumsq = moments[0].contiguous(), moments[1].contiguous()
     state.n = int(count.item())
     if state.hist is not None:
         if state.n > 65535:
             raise ValueError(f"uint16 histogram holds at most 65,535 samples per row (n = {state.n})")
-        dist.all_reduce(state.hist.view(torch.int32), group=group)
+        all_reduce_sum(state.hist.view(torch.int32), group)
     return state
 
 
@@ -140,12 +159,17 @@ def scatter_combine(state: ReduceState, group=None) -> Tuple[ReduceState, int, i
     def exchange(t: torch.Tensor) -> torch.Tensor:
         # rows travel as raw bytes: no arithmetic happens on the wire, and gloo's all_to_all has no int16
         src = t.contiguous().view(B, -1).view(torch.uint8)
-        out = torch.empty(world * mine, src.shape[1], dtype=torch.uint8, device=t.device)
+        host = _via_host(t, group)  # gloo rehearsal on a shared GPU only (see all_reduce_sum)
+        if host:
+            src = src.cpu()
+        out = torch.empty(world * mine, src.shape[1], dtype=torch.uint8, device=src.device)
         dist.all_to_all_single(out, src, output_split_sizes=[mine] * world, input_split_sizes=send_rows, group=group)
+        if host:
+            out = out.to(t.device)
         return out.view(t.dtype).view((world, mine) + tuple(t.shape[1:]))
 
     count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
-    dist.all_reduce(count, group=group)
+    all_reduce_sum(count, group)
     n = int(count.item())
     out = ReduceState(n, exchange(state.sum).sum(0), exchange(state.sumsq).sum(0), nbins=state.nbins)
     if state.hist is not None:
@@ -171,8 +195,13 @@ def gather_rows(parts: Sequence[Optional[torch.Tensor]], B: int, group=None) -> 
     packed = torch.zeros(K, per, dtype=torch.float32, device=present[0].device)
     if r1 > r0:
         packed[:, :r1 - r0] = torch.cat(blocks, dim=0)
+    host = _via_host(packed, group)
+    if host:
+        packed = packed.cpu()
     gathered = torch.empty(world * K, per, dtype=torch.float32, device=packed.device)  # concatenated along dim 0
     dist.all_gather_into_tensor(gathered, packed, group=group)
+    if host:
+        gathered = gathered.to(present[0].device)
     full = gathered.view(world, K, per).permute(1, 0, 2).reshape(K, world * per)[:, :B]
     outs, k = [], 0
     for t in parts:

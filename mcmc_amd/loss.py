@@ -13,7 +13,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .engine import Engine, _p, _require_gpu, _stream
+from .engine import Engine, _p, _require_gpu, _stream, all_reduce_sum
 
 
 def _is_dist() -> bool:
@@ -25,8 +25,7 @@ def _allreduce(t: torch.Tensor, group):
     """group False: local statistics (reference semantics); None / a group: global-batch."""
     if group is False or not _is_dist():
         return
-    import torch.distributed as dist
-    dist.all_reduce(t, group=group)
+    all_reduce_sum(t, group)
 
 
 class _PeakWeightedLoss(torch.autograd.Function):

@@ -20,11 +20,19 @@ import torch
 
 from . import _lib
 from ._lib import NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX
-from .engine import HIDDEN, Engine, _p, _stream, param_count
+from .engine import HIDDEN, Engine, _p, _stream, all_reduce_sum, param_count
 
 MASK_NONE, MASK_HOST, MASK_PHILOX = 0, 1, 2
 _GOLDEN = 0x9E3779B97F4A7C15
 _U64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _dp_world(group) -> int:
+    """Ranks the step's rows are sharded over: 1 without torch.distributed or with group=False."""
+    import torch.distributed as dist
+    if group is False or not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(group)
 
 
 class EnsembleTrainer:
@@ -55,15 +63,15 @@ class EnsembleTrainer:
         self.W = torch.empty(pairs, self.P, **f32)
         self.WT = torch.empty(pairs, self.P, **f32)
         self.dW = torch.empty(pairs, self.P, **f32)
-        self.gmu = torch.empty(self.M, self.P, **f32)
-        self.grho = torch.empty(self.M, self.P, **f32)
+        self.grad = torch.empty(2, self.M, self.P, **f32)  # one buffer: the data-parallel step all-reduces it in one call
+        self.gmu, self.grho = self.grad[0], self.grad[1]
         self.adam_m = torch.zeros(self.M, 2 * self.P, **f32)
         self.adam_v = torch.zeros(self.M, 2 * self.P, **f32)
         self.norm_scratch = torch.empty(self.M * self.eng.lib.mcmc_train_norm_blocks(), dtype=torch.float64, device=dev)
         self.gnorm = torch.empty(self.M, **f32)
         self.loss = torch.empty(self.M, **f32)
         self.t = 0  # AdamW step count (shared: all members start together; frozen members never resume)
-        self._Y = self._delta = None
+        self._Y = self._delta = self._dpbuf = None
         h = self.eng.ctx.handle
         _lib.check(self.eng.lib.mcmc_train_sigma(h, _p(self.rho), _p(self.sigma), self.rho.numel(), _stream()), "mcmc_train_sigma")
 
@@ -76,7 +84,7 @@ class EnsembleTrainer:
     def step(self, xb: torch.Tensor, yb: torch.Tensor, lr: float, beta1: float = 0.9, *, noise: str = "philox",
              eps: Optional[torch.Tensor] = None, seed: int = 0, masks: Optional[Sequence[torch.Tensor]] = None,
              mask_seed: Optional[int] = None, dropout: bool = True, active: Optional[torch.Tensor] = None,
-             update: bool = True) -> torch.Tensor:
+             update: bool = True, group=False, global_rows: Optional[int] = None) -> torch.Tensor:
         """One optimisation step of every (active) member.
 
         xb [M,rows,F], yb [M,rows] fp32 on the device.  noise: 'philox' (keyed by ``seed``),
@@ -84,7 +92,16 @@ class EnsembleTrainer:
         [M*S,rows,256/128/64]) when ``masks`` is given, else Philox masks keyed by ``mask_seed``
         (default: seed), or none with dropout=False.  ``active`` [M] uint8 on the device freezes
         members whose flag is 0 (early-stopped; they must not be re-activated later, the AdamW step
-        count is shared).  Returns the per-member loss [M] (device tensor, no sync)."""
+        count is shared).  Returns the per-member loss [M] (device tensor, no sync).
+
+        Data-parallel (BASELINE config 5): with torch.distributed initialised and
+        ``group`` None (the default process group) or a group, xb / yb are THIS rank's rows of every member's batch.  Noise is keyed by
+        (seed, pair) so every rank draws the same weights; the loss statistics (mean / std of y,
+        mean |e|, G) are global-batch through two all-reduces of [M,4] fp64 partials, each rank
+        back-propagates its rows, and (gmu, grho) are sum-all-reduced (2*M*P fp32 = 354 KB per member)
+        before the clip and the AdamW update, which every rank then applies identically.
+        ``global_rows``: total rows per member over all ranks (saves the sync that counts them).
+        Philox dropout masks are keyed by the rank-local row index (use distinct mask_seed per rank)."""
         lib, h = self.eng.lib, self.eng.ctx.handle
         M, S, F = self.M, self.S, self.F
         if xb.dim() != 3 or xb.shape[0] != M or xb.shape[2] != F:
@@ -117,17 +134,59 @@ class EnsembleTrainer:
                                          _p(self.W), _p(self.WT), st), "mcmc_train_sample")
         _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed, self.p_drop,
                                           _p(Y), st), "mcmc_train_forward")
-        _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, self.alpha, self.beta, _p(delta), _p(self.loss), st),
-                   "mcmc_train_loss")
+        dp = _dp_world(group) > 1
+        if dp:
+            self._dp_loss(Y, yb, rows, delta, group, global_rows)
+        else:
+            _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, self.alpha, self.beta, _p(delta), _p(self.loss), st),
+                       "mcmc_train_loss")
         _lib.check(lib.mcmc_train_backward(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
                                            self.p_drop, _p(delta), _p(self.dW), st), "mcmc_train_backward")
-        if update:
+        if update and dp:
+            self.t += 1
+            _lib.check(lib.mcmc_train_grad(h, M, S, F, _p(self.eps), _p(self.sigma), _p(self.dW), _p(self.gmu), _p(self.grho),
+                                           _p(self.norm_scratch), st), "mcmc_train_grad")
+            all_reduce_sum(self.grad, group)
+            _lib.check(lib.mcmc_train_apply(h, _p(self.mu), _p(self.rho), _p(self.sigma), M, F, _p(self.gmu), _p(self.grho),
+                                            _p(self.adam_m), _p(self.adam_v), _p(self.norm_scratch), _p(active), lr, beta1, self.beta2,
+                                            self.adam_eps, self.weight_decay, self.max_norm, self.t, _p(self.gnorm), st),
+                       "mcmc_train_apply")
+        elif update:
             self.t += 1
             _lib.check(lib.mcmc_train_update(h, _p(self.mu), _p(self.rho), _p(self.sigma), M, S, F, _p(self.eps), _p(self.dW),
                                              _p(self.gmu), _p(self.grho), _p(self.adam_m), _p(self.adam_v), _p(self.norm_scratch),
                                              _p(active), lr, beta1, self.beta2, self.adam_eps, self.weight_decay, self.max_norm,
                                              self.t, _p(self.gnorm), st), "mcmc_train_update")
         return self.loss
+
+    def _dp_loss(self, Y: torch.Tensor, yb: torch.Tensor, rows: int, delta: torch.Tensor, group, global_rows: Optional[int]):
+        """peak_weighted_loss with global-batch statistics on the piece-3 kernels (mcmc_loss_*): per member
+        p = mean over samples of this rank's rows; partial sums all-reduced between the passes."""
+        import torch.distributed as dist
+        lib, h, st = self.eng.lib, self.eng.ctx.handle, _stream()
+        M, S, dev = self.M, self.S, self.eng.device
+        rp = (rows + 3) // 4 * 4  # 16-byte aligned member rows
+        if self._dpbuf is None or self._dpbuf.shape[2] != rp:
+            self._dpbuf = torch.zeros(3, M, rp, dtype=torch.float32, device=dev)
+        pbuf, tbuf, dbuf = self._dpbuf[0], self._dpbuf[1], self._dpbuf[2]
+        pbuf[:, :rows] = Y.view(M, S, rows).mean(1)  # bayesian_ensemble.py:173-174
+        tbuf[:, :rows] = yb
+        acc = torch.zeros(2, M, 4, dtype=torch.float64, device=dev)
+        stats, part = acc[0], acc[1]
+        stats[:, 3] = rows
+        for m in range(M):
+            _lib.check(lib.mcmc_loss_stats(h, _p(pbuf[m]), _p(tbuf[m]), rows, _p(stats[m]), st), "mcmc_loss_stats")
+        all_reduce_sum(stats, group)
+        n_total = int(global_rows) if global_rows is not None else int(round(float(stats[0, 3].item())))
+        for m in range(M):
+            _lib.check(lib.mcmc_loss_forward(h, _p(pbuf[m]), _p(tbuf[m]), rows, n_total, _p(stats[m]), self.alpha, self.beta,
+                                             _p(part[m]), st), "mcmc_loss_forward")
+        all_reduce_sum(part, group)
+        self.loss = (part[:, 0] / n_total).to(torch.float32)
+        for m in range(M):
+            _lib.check(lib.mcmc_loss_backward(h, _p(pbuf[m]), _p(tbuf[m]), rows, n_total, _p(stats[m]), _p(part[m]), self.alpha,
+                                              self.beta, 1.0 / S, _p(dbuf[m]), st), "mcmc_loss_backward")
+        delta.copy_(dbuf[:, :rows])
 
     def predictions(self) -> torch.Tensor:
         """Y [M*S, rows] of the last step's train-mode forwards."""

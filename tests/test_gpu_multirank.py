@@ -1,0 +1,30 @@
+"""Two ranks sharing the one GPU of the test box (gloo between them) run the real kernels through the
+multi-rank host logic: pair-sharded predict with the reduce-scatter exchange, the data-parallel loss and
+the data-parallel training step, each compared with a single-rank run (tools/check_multirank.py).
+
+The file sorts before the other GPU tests on purpose: the ranks are child processes, started before this
+process has touched the GPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_match_single_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MCMC_CHECK_TIMEOUT=os.environ.get("MCMC_CHECK_TIMEOUT", "150"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "check_multirank.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):  # keep the ranks' output where a GPU session can read it back
+        with open(os.path.join(out_dir, "multirank_test.log"), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    assert r.returncode == 0 and "multirank OK: world=2" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

@@ -52,9 +52,9 @@ def main():
         bad = ((shard.quantiles - alone.quantiles).abs() > width)
         assert not bool(bad.any()), (dtype, int(bad.sum()), float(((shard.quantiles - alone.quantiles).abs() / width).max()))
         # all ranks hold the same full result
-        ref = shard.mean.clone()
+        ref = shard.mean.cpu()  # host tensors: also valid when the ranks share one GPU over gloo
         dist.broadcast(ref, src=0)
-        assert torch.equal(ref, shard.mean)
+        assert torch.equal(ref, shard.mean.cpu())
     # loss, rows split over ranks, global-batch statistics
     N = 4099
     t = torch.randn(N, generator=g)
@@ -69,6 +69,34 @@ def main():
     full.backward()
     assert abs(float(loss) - float(full)) <= 2e-6 * abs(float(full)), (float(loss), float(full))
     assert torch.allclose(p_loc.grad, p_all.grad[sl], rtol=1e-5, atol=1e-9)
+    # data-parallel training step (BASELINE config 5): every member's batch rows split over the ranks ==
+    # one process on the whole batch (same injected noise and dropout masks)
+    from mcmc_amd.train import EnsembleTrainer
+    M2, S2, rows, lr = 2, 3, 45, 0.01
+    mu0 = (torch.randn(M2, P, generator=g) * 0.08).to(dev)
+    rho0 = (-3.0 + 0.3 * torch.randn(M2, P, generator=g)).to(dev)
+    xb = torch.randn(M2, rows, F, generator=g).to(dev)
+    yb = torch.randn(M2, rows, generator=g).to(dev)
+    eps = torch.randn(M2, S2, P, generator=g).to(dev)
+    masks = [(torch.rand(M2 * S2, rows, w, generator=g) < 0.9).to(torch.uint8).to(dev) for w in (256, 128, 64)]
+    per = (rows + world - 1) // world
+    sl = slice(rank * per, min(rows, (rank + 1) * per))
+    whole, shard = EnsembleTrainer(mu0, rho0, F, S2), EnsembleTrainer(mu0, rho0, F, S2)
+    steps = 3
+    for _ in range(steps):
+        lw = whole.step(xb, yb, lr, 0.9, noise="injected", eps=eps, masks=masks, group=False)
+        ls = shard.step(xb[:, sl], yb[:, sl], lr, 0.9, noise="injected", eps=eps, masks=[m[:, sl] for m in masks], group=None,
+                        global_rows=rows)
+        assert torch.allclose(lw, ls, rtol=2e-5, atol=1e-7), (lw.tolist(), ls.tolist())
+        gscale = float(whole.grad.abs().max())
+        assert float((whole.grad - shard.grad).abs().max()) <= 1e-4 * gscale, float((whole.grad - shard.grad).abs().max()) / gscale
+        assert torch.allclose(whole.gnorm, shard.gnorm, rtol=1e-5)
+    for a, b in ((whole.mu, shard.mu), (whole.rho, shard.rho)):
+        diff = (a - b).abs()
+        assert float((diff <= 2e-6).float().mean()) >= 0.999 and float(diff.max()) <= 2.1 * lr * steps, (float(diff.max()),)
+    ref = shard.mu.cpu()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(ref, shard.mu.cpu())  # every rank applied the same update
     dist.barrier()
     if rank == 0:
         print(f"multirank OK: world={world} backend={backend} gpus={ngpu}")
