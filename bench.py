@@ -12,7 +12,7 @@ With N > 1 the 8,192 (member, sample) pairs are sharded over the ranks; the part
 histogram) are reduce-scattered over rows on RCCL, each rank finalizes its row slice and the
 results are all-gathered: total work is fixed -> "strong" scaling.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (forward_bf16_kernel):
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (forward_bf16_tiles_kernel):
 algorithmic FLOPs (87,680 per unit) / launch duration measured with events on
 the launch stream.  `cpu_baseline` times the CPU oracle (reference predict() op sequence in
 torch-CPU, oracle/bnn_oracle.py) on a bounded sample of the same workload on this host.
@@ -175,7 +175,7 @@ def main():
             "config": {"workload": f"{args.series} series x 365 steps x {args.members} members x {args.samples} MC samples, "
                                    f"input_dim {X.shape[1]}, Philox weight noise, mean+std+95% interval ({args.nbins}-bin histogram)",
                        "units_per_step": units_per_step, "pairs_sharded_over": world},
-            "roofline": {"bound": "mfma", "kernel": "forward_bf16_kernel", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "forward_bf16_tiles_kernel", "achieved": achieved, "peak": PEAK_BF16_DENSE / 1e12,
                          "unit": "TFLOP/s", "frac": achieved * 1e12 / PEAK_BF16_DENSE,
                          "traffic": load_traffic(fwd_units / max(len(fwd_ms), 1)),
                          "launches": len(fwd_ms), "avg_launch_ms": (sum(fwd_ms) / len(fwd_ms)) if fwd_ms else None,

@@ -152,18 +152,142 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
     }
 }
 
-template <int KS0, int kWaves>
+// Variant with T row tiles per wave: every A fragment read from LDS feeds T MFMAs (T x fewer LDS bytes and
+// ds_read instructions per row), and the T independent tiles give the wave its own instruction-level
+// parallelism, so fewer, fatter waves (256 registers at 8 waves per CU) keep the SIMD's issue port fed.
+// Layers are interleaved explicitly: each 32-feature tile of a layer is activated, packed and consumed by the
+// next layer's MFMAs at once, so only one tile's bf16 fragments are live (same accumulation order as above:
+// bitwise-identical results).
+template <int KS0, int kWaves, int T>
+__global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_kernel(const unsigned short* __restrict__ xpack,
+                                                                            int64_t n_rows, int F, int rows_per_block,
+                                                                            const unsigned char* __restrict__ wpack,
+                                                                            float* __restrict__ Y, int64_t ldY) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const WPackBF16 L(F);
+    constexpr int ks0 = KS0;
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(wpack + (int64_t)c * L.total);
+        uint4* dst = reinterpret_cast<uint4*>(lds);
+        for (int i = threadIdx.x; i < (int)(L.total / 16); i += 64 * kWaves) dst[i] = src[i];
+    }
+    __syncthreads();
+    const bf16x8* A0 = reinterpret_cast<const bf16x8*>(lds + L.l0) + lane;
+    const bf16x8* A1 = reinterpret_cast<const bf16x8*>(lds + L.l1) + lane;
+    const bf16x8* A2 = reinterpret_cast<const bf16x8*>(lds + L.l2) + lane;
+    const float* B1 = reinterpret_cast<const float*>(lds + L.b1) + h * 16;
+    const float* B2 = reinterpret_cast<const float*>(lds + L.b2) + h * 16;
+    const float* W3 = reinterpret_cast<const float*>(lds + L.w3) + h * 16;
+    const float b3 = *reinterpret_cast<const float*>(lds + L.b3);
+
+    const int64_t padded = rows_pad(n_rows);
+    const int64_t blk_begin = (int64_t)blockIdx.y * rows_per_block;
+    int64_t blk_end = blk_begin + rows_per_block;
+    if (blk_end > padded) blk_end = padded;
+
+    for (int64_t row0 = blk_begin + 32 * T * wave; row0 < blk_end; row0 += 32 * T * kWaves) {
+        asm volatile("" ::: "memory");
+        bf16x8 xb[T][KS0];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int64_t row = row0 + 32 * t + r;
+            if (row >= padded) row = padded - 1;  // a tile past the end recomputes the last row; nothing is stored
+#pragma unroll
+            for (int s = 0; s < KS0; ++s) xb[t][s] = *reinterpret_cast<const bf16x8*>(xpack + row * L.K0 + 16 * s + 8 * h);
+        }
+        // ---- layers 0 and 1 interleaved ----
+        f32x16 acc1[T][4];
+#pragma unroll
+        for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float b = B1[mo * 32 + i];
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc1[t][mo][i] = b;
+            }
+#pragma unroll
+        for (int m0 = 0; m0 < 8; ++m0) {
+            bf16x8 lo[T], hi[T];
+            f32x16 a0[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) a0[t] = f32x16{0};
+#pragma unroll
+            for (int s = 0; s < KS0; ++s) {
+                const bf16x8 fa = A0[(m0 * ks0 + s) * 64];
+#pragma unroll
+                for (int t = 0; t < T; ++t) a0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xb[t][s], a0[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) pack16(a0[t], lo[t], hi[t]);
+#pragma unroll
+            for (int mo = 0; mo < 4; ++mo) {
+                const bf16x8 fa = A1[(mo * 16 + 2 * m0) * 64], fb = A1[(mo * 16 + 2 * m0 + 1) * 64];
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc1[t][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lo[t], acc1[t][mo], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc1[t][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, hi[t], acc1[t][mo], 0, 0, 0);
+            }
+        }
+        // ---- layers 1 (activation) and 2 interleaved ----
+        f32x16 acc2[T][2];
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float b = B2[mo * 32 + i];
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc2[t][mo][i] = b;
+            }
+#pragma unroll
+        for (int m1 = 0; m1 < 4; ++m1) {
+            bf16x8 lo[T], hi[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) pack16(acc1[t][m1], lo[t], hi[t]);
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo) {
+                const bf16x8 fa = A2[(mo * 8 + 2 * m1) * 64], fb = A2[(mo * 8 + 2 * m1 + 1) * 64];
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc2[t][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lo[t], acc2[t][mo], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc2[t][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, hi[t], acc2[t][mo], 0, 0, 0);
+            }
+        }
+        // ---- layer 2 activation, layer 3 on the VALU ----
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float y = 0.0f;
+#pragma unroll
+            for (int mo = 0; mo < 2; ++mo) {
+                float o[16];
+                phi16(acc2[t][mo], o);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y = fmaf(W3[mo * 32 + i], o[i], y);
+            }
+            y += __shfl_xor(y, 32);
+            y += b3;
+            const int64_t row = row0 + 32 * t + r;
+            if (h == 0 && row < n_rows && row0 + 32 * t < blk_end) Y[(int64_t)c * ldY + row] = y;
+        }
+    }
+}
+
+template <int KS0, int kWaves, int T = 1>
 static int launch_variant(const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count, float* Y, int64_t ldY,
                           hipStream_t s) {
     const WPackBF16 L(F);
     const size_t lds_bytes = (size_t)L.total;
-    auto kern = forward_bf16_kernel<KS0, kWaves>;
+    void (*kern)(const unsigned short*, int64_t, int, int, const unsigned char*, float*, int64_t);
+    if constexpr (T == 1) kern = forward_bf16_kernel<KS0, kWaves>;
+    else kern = forward_bf16_tiles_kernel<KS0, kWaves, T>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_bf16, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
     // Row superblock: large enough that staging 89 KB of weights is ~1 % of its MFMA time
     // (64 tiles per wave at 8 waves), small enough that pairs x superblocks >> 256 CUs.
     const int64_t padded = rows_pad(n_rows);
-    const int step = 32 * kWaves;
+    const int step = 32 * kWaves * T;
     int rows_per_block = 16384 / step * step;
     if (padded < rows_per_block) rows_per_block = (int)((padded + step - 1) / step * step);
     const int64_t row_blocks = (padded + rows_per_block - 1) / rows_per_block;
@@ -188,6 +312,16 @@ int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, 
         return (w == 8 || w == 12 || w == 16) ? w : kDefaultWaves;  // 16 falls back to 12 when input_dim > 14
     }();
     const bool one = WPackBF16(F).K0 == 16;
+    // Default: two row tiles per wave at 8 waves per workgroup (measured 33.4 vs 34.0 ms for one tile per wave at
+    // 16 waves, 365k rows x 1024 pairs).  MCMC_FWD_TILES=1 selects the one-tile kernel (dev knob).
+    static const int tiles = [] {
+        const char* e = getenv("MCMC_FWD_TILES");
+        return e ? atoi(e) : 2;
+    }();
+    if (tiles != 1) {
+        if (one) return launch_variant<1, 8, 2>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s);
+        return launch_variant<2, 8, 2>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s);
+    }
 #define MCMC_GO(KS, W) return launch_variant<KS, W>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s)
     if (one) {
         if (waves == 16) MCMC_GO(1, 16);
