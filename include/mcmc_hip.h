@@ -99,12 +99,23 @@ int mcmc_philox_eps(mcmc_ctx* ctx, uint64_t seed, int64_t g_begin, int pair_coun
  * Y[c*ldY + row] = y of pair c, row (fp32).  ldY >= n_rows, multiple of 4.
  *   mask0/1/2 : optional uint8 keep-masks [pair_count, n_rows, 256/128/64] (train-mode dropout,
  *               bayesian_ensemble.py:86); NULL = identity (eval mode, what predict() runs,
- *               bayesian_ensemble.py:215-216).  keep_scale = fp32(1/(1-p)).
- *               Masks are supported for MCMC_DT_F32 only. */
+ *               bayesian_ensemble.py:215-216).  keep_scale = fp32(1/(1-p)).  4-byte aligned.
+ *               Both dtypes apply them inside the MFMA kernel's activation stage. */
 int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim,
                  const void* wpack, int pair_count, const uint8_t* mask0, const uint8_t* mask1,
                  const uint8_t* mask2, float keep_scale, float* Y, int64_t ldY,
                  mcmc_stream_t stream);
+
+/* The same forward with counter-based dropout masks (train-mode forward, bayesian_ensemble.py:86,
+ * :158; an opt-in MC-dropout predict - the reference's predict() itself runs in eval mode): the
+ * keep flag of hidden activation elem (0..447 over the three layers) of global pair id
+ * g = (q % n_members) * n_samples + q / n_members, q = pair_begin + c, and batch row `row` is
+ * u01(Philox4x32-10(counter (elem>>2, g, 'MASK', row), key mask_seed)[elem&3]) < 1 - p_drop:
+ * the stream of mcmc_train_forward's mask_mode 2, so predict and train see the same masks. */
+int mcmc_forward_dropout(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows,
+                         int input_dim, const void* wpack, int n_members, int n_samples,
+                         int64_t pair_begin, int pair_count, uint64_t mask_seed, float p_drop,
+                         float* Y, int64_t ldY, mcmc_stream_t stream);
 
 /* ---- piece 2: streaming per-timestep statistics ------------------------------------------- */
 /* Replaces torch.stack + reshape + mean(0) + std(0) (bayesian_ensemble.py:234-246) without

@@ -134,8 +134,10 @@ class GPUBayesianEnsemble(nn.Module):
     def predict_full(self, X: torch.Tensor, num_samples: int = 100, *, dtype: Optional[str] = None,
                      quantiles: Sequence[float] = (0.025, 0.975), nbins: int = 128, noise: str = "philox",
                      eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, group=None,
-                     return_samples: bool = False, chunk_pairs: Optional[int] = None) -> engine.PredictResult:
-        """predict() plus the extensions (interval quantiles, injected noise, bf16, sharding)."""
+                     return_samples: bool = False, chunk_pairs: Optional[int] = None, mc_dropout: bool = False,
+                     mask_seed: Optional[int] = None) -> engine.PredictResult:
+        """predict() plus the extensions (interval quantiles, injected noise, bf16, sharding, MC dropout:
+        ``mc_dropout=True`` keeps Dropout(0.1) live with Philox masks; the reference's predict() is eval-mode)."""
         if not self.models:
             raise RuntimeError("no trained members: call train() or fill .models first")
         for model in self.models:
@@ -147,7 +149,8 @@ class GPUBayesianEnsemble(nn.Module):
         with torch.no_grad():
             return engine.mc_predict(X, mu, rho, num_samples, dtype=dtype or self.compute_dtype, noise=noise, eps=eps,
                                      seed=self._next_seed() if seed is None else seed, q_levels=tuple(quantiles), nbins=nbins,
-                                     group=group, return_samples=return_samples, chunk_pairs=chunk_pairs)
+                                     group=group, return_samples=return_samples, chunk_pairs=chunk_pairs, mc_dropout=mc_dropout,
+                                     mask_seed=mask_seed)
 
     def predict(self, X: torch.Tensor, num_samples: int = 100) -> Tuple[torch.Tensor, torch.Tensor]:
         """Generate predictions with uncertainty estimates (bayesian_ensemble.py:212-252):

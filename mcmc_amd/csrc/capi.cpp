@@ -5,6 +5,7 @@
 #include <new>
 
 #include "common.hpp"
+#include "dropmask.hpp"
 
 namespace mcmc {
 
@@ -34,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 5; }
+int mcmc_abi_version(void) { return 6; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -133,9 +134,8 @@ int mcmc_philox_eps(mcmc_ctx* ctx, uint64_t seed, int64_t g_begin, int pair_coun
     return launch_philox_eps(seed, g_begin, pair_count, input_dim, eps, (hipStream_t)stream);
 }
 
-int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int pair_count,
-                 const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, float keep_scale, float* Y, int64_t ldY,
-                 mcmc_stream_t stream) {
+static int forward_impl(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int pair_count,
+                        const DropMask* dm, float* Y, int64_t ldY, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_dims(input_dim, dtype)) return rc;
     MCMC_REQUIRE(n_rows >= 0 && pair_count >= 0, "n_rows / pair_count < 0");
@@ -143,13 +143,47 @@ int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, in
     MCMC_REQUIRE(xpack && wpack && Y, "xpack / wpack / Y is NULL");
     MCMC_REQUIRE(aligned16(xpack) && aligned16(wpack), "xpack and wpack must be 16-byte aligned");
     MCMC_REQUIRE(ldY >= n_rows && ldY % 4 == 0, "ldY must be >= n_rows and a multiple of 4 (got %lld)", (long long)ldY);
+    if (dtype == DT_F32)
+        return launch_forward_f32((const float*)xpack, n_rows, input_dim, (const float*)wpack, pair_count, dm, Y, ldY, (hipStream_t)stream);
+    return launch_forward_bf16(ctx, xpack, n_rows, input_dim, wpack, pair_count, dm, Y, ldY, (hipStream_t)stream);
+}
+
+int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int pair_count,
+                 const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, float keep_scale, float* Y, int64_t ldY,
+                 mcmc_stream_t stream) {
     const bool any = mask0 || mask1 || mask2, all = mask0 && mask1 && mask2;
     MCMC_REQUIRE(any == all, "dropout masks: pass all three or none");
-    if (dtype == DT_F32)
-        return launch_forward_f32((const float*)xpack, n_rows, input_dim, (const float*)wpack, pair_count, mask0, mask1, mask2,
-                                  keep_scale, Y, ldY, (hipStream_t)stream);
-    MCMC_REQUIRE(!any, "dropout masks are supported for MCMC_DT_F32 only");
-    return launch_forward_bf16(ctx, xpack, n_rows, input_dim, wpack, pair_count, Y, ldY, (hipStream_t)stream);
+    if (!any) return forward_impl(ctx, dtype, xpack, n_rows, input_dim, wpack, pair_count, nullptr, Y, ldY, stream);
+    MCMC_REQUIRE((reinterpret_cast<uintptr_t>(mask0) & 3u) == 0 && (reinterpret_cast<uintptr_t>(mask1) & 3u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(mask2) & 3u) == 0,
+                 "dropout masks must be 4-byte aligned");
+    DropMask dm{};
+    dm.m[0] = mask0;
+    dm.m[1] = mask1;
+    dm.m[2] = mask2;
+    dm.mode = 1;
+    dm.scale = keep_scale;
+    dm.M = dm.S = 1;
+    return forward_impl(ctx, dtype, xpack, n_rows, input_dim, wpack, pair_count, &dm, Y, ldY, stream);
+}
+
+int mcmc_forward_dropout(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int n_members,
+                         int n_samples, int64_t pair_begin, int pair_count, uint64_t mask_seed, float p_drop, float* Y, int64_t ldY,
+                         mcmc_stream_t stream) {
+    MCMC_REQUIRE(n_members >= 1 && n_samples >= 1, "n_members and n_samples must be >= 1");
+    MCMC_REQUIRE(pair_begin >= 0 && pair_count >= 0 && pair_begin + pair_count <= (int64_t)n_members * n_samples,
+                 "pair range [%lld, +%d) outside n_members*n_samples", (long long)pair_begin, pair_count);
+    MCMC_REQUIRE((int64_t)n_members * n_samples <= 0x7FFFFFFFLL && n_rows <= 0xFFFFFFFFLL, "pair or row index exceeds the 32-bit Philox counter");
+    MCMC_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "p_drop must be in [0, 1)");
+    DropMask dm{};
+    dm.seed = mask_seed;
+    dm.mode = 2;
+    dm.keep_prob = 1.0f - p_drop;
+    dm.scale = (float)(1.0 / (1.0 - (double)p_drop));  // torch: scale = 1/(1-p) in double, applied as fp32
+    dm.M = n_members;
+    dm.S = n_samples;
+    dm.pair_begin = pair_begin;
+    return forward_impl(ctx, dtype, xpack, n_rows, input_dim, wpack, pair_count, &dm, Y, ldY, stream);
 }
 
 static int check_nbins(int nbins) {

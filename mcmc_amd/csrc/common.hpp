@@ -48,11 +48,11 @@ int launch_sample_weights(const float* mu, const float* rho, int M, int S, int F
                           int noise_mode, const float* eps, uint64_t seed, const uint64_t* seed_dev, int dtype, void* wpack,
                           hipStream_t s);
 int launch_philox_eps(uint64_t seed, int64_t g_begin, int pair_count, int F, float* eps, hipStream_t s);
-int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count,
-                       const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, float keep_scale, float* Y, int64_t ldY,
-                       hipStream_t s);
+struct DropMask;  // dropmask.hpp; NULL or mode 0 = eval-mode forward
+int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count, const DropMask* dm, float* Y,
+                       int64_t ldY, hipStream_t s);
 int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
-                        float* Y, int64_t ldY, hipStream_t s);
+                        const DropMask* dm, float* Y, int64_t ldY, hipStream_t s);
 int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
                          double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s);
 int launch_set_edges(int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins, float range_sigmas,

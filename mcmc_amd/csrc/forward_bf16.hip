@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.hpp"
+#include "dropmask.hpp"
 
 namespace mcmc {
 
@@ -44,15 +45,18 @@ __device__ __forceinline__ void phi16(const f32x16& acc, float (&o)[16]) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = acc[i];
 #else
+#ifndef MCMC_PHI_GROUP
+#define MCMC_PHI_GROUP 8
+#endif
 #pragma unroll
-    for (int g = 0; g < 16; g += 8) {
-        float t[8];
+    for (int g = 0; g < 16; g += MCMC_PHI_GROUP) {
+        float t[MCMC_PHI_GROUP];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(acc[g + i]), 0.0f, 1.0f);  // v_exp_f32 clamp
+        for (int i = 0; i < MCMC_PHI_GROUP; ++i) t[i] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(acc[g + i]), 0.0f, 1.0f);  // v_exp_f32 clamp
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = fmaf(t[i], kLog2e, -kLog2e);
+        for (int i = 0; i < MCMC_PHI_GROUP; ++i) t[i] = fmaf(t[i], kLog2e, -kLog2e);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[g + i] = max_nc(acc[g + i], t[i]);
+        for (int i = 0; i < MCMC_PHI_GROUP; ++i) o[g + i] = max_nc(acc[g + i], t[i]);
     }
 #endif
 }
@@ -60,6 +64,20 @@ __device__ __forceinline__ void phi16(const f32x16& acc, float (&o)[16]) {
 __device__ __forceinline__ void pack16(const f32x16& acc, bf16x8& lo, bf16x8& hi) {
     float o[16];
     phi16(acc, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        lo[j] = (__bf16)o[j];
+        hi[j] = (__bf16)o[8 + j];
+    }
+}
+
+// phi + dropout + bf16 pack of hidden-layer tile `mo` (MODE 0: exactly pack16)
+template <int MODE>
+__device__ __forceinline__ void pack16_drop(const f32x16& acc, bf16x8& lo, bf16x8& hi, const DropMask& dm, int layer, int mo, int h,
+                                            int c, uint32_t g, int64_t n_rows, int64_t row) {
+    float o[16];
+    phi16(acc, o);
+    drop16<MODE>(o, dm, layer, mo, h, c, g, n_rows, row);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         lo[j] = (__bf16)o[j];
@@ -158,11 +176,11 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_kernel(c
 // Layers are interleaved explicitly: each 32-feature tile of a layer is activated, packed and consumed by the
 // next layer's MFMAs at once, so only one tile's bf16 fragments are live (same accumulation order as above:
 // bitwise-identical results).
-template <int KS0, int kWaves, int T>
+template <int KS0, int kWaves, int T, int MODE>
 __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_kernel(const unsigned short* __restrict__ xpack,
                                                                             int64_t n_rows, int F, int rows_per_block,
                                                                             const unsigned char* __restrict__ wpack,
-                                                                            float* __restrict__ Y, int64_t ldY) {
+                                                                            float* __restrict__ Y, int64_t ldY, DropMask dm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const WPackBF16 L(F);
     constexpr int ks0 = KS0;
@@ -188,6 +206,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_ke
     int64_t blk_end = blk_begin + rows_per_block;
     if (blk_end > padded) blk_end = padded;
 
+    const uint32_t g = MODE == 2 ? drop_pair_id(dm, c) : 0u;
     for (int64_t row0 = blk_begin + 32 * T * wave; row0 < blk_end; row0 += 32 * T * kWaves) {
         asm volatile("" ::: "memory");
         bf16x8 xb[T][KS0];
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_ke
                 for (int t = 0; t < T; ++t) a0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, xb[t][s], a0[t], 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < T; ++t) pack16(a0[t], lo[t], hi[t]);
+            for (int t = 0; t < T; ++t) pack16_drop<MODE>(a0[t], lo[t], hi[t], dm, 0, m0, h, c, g, n_rows, row0 + 32 * t + r);
 #pragma unroll
             for (int mo = 0; mo < 4; ++mo) {
                 const bf16x8 fa = A1[(mo * 16 + 2 * m0) * 64], fb = A1[(mo * 16 + 2 * m0 + 1) * 64];
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_ke
         for (int m1 = 0; m1 < 4; ++m1) {
             bf16x8 lo[T], hi[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) pack16(acc1[t][m1], lo[t], hi[t]);
+            for (int t = 0; t < T; ++t) pack16_drop<MODE>(acc1[t][m1], lo[t], hi[t], dm, 1, m1, h, c, g, n_rows, row0 + 32 * t + r);
 #pragma unroll
             for (int mo = 0; mo < 2; ++mo) {
                 const bf16x8 fa = A2[(mo * 8 + 2 * m1) * 64], fb = A2[(mo * 8 + 2 * m1 + 1) * 64];
@@ -263,6 +282,7 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_ke
             for (int mo = 0; mo < 2; ++mo) {
                 float o[16];
                 phi16(acc2[t][mo], o);
+                drop16<MODE>(o, dm, 2, mo, h, c, g, n_rows, row0 + 32 * t + r);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) y = fmaf(W3[mo * 32 + i], o[i], y);
             }
@@ -274,28 +294,46 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_tiles_ke
     }
 }
 
-template <int KS0, int kWaves, int T = 1>
+template <int KS0, int kWaves, int T = 1, int MODE = 0>
 static int launch_variant(const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count, float* Y, int64_t ldY,
-                          hipStream_t s) {
+                          hipStream_t s, const DropMask& dm = DropMask{}) {
     const WPackBF16 L(F);
     const size_t lds_bytes = (size_t)L.total;
-    void (*kern)(const unsigned short*, int64_t, int, int, const unsigned char*, float*, int64_t);
-    if constexpr (T == 1) kern = forward_bf16_kernel<KS0, kWaves>;
-    else kern = forward_bf16_tiles_kernel<KS0, kWaves, T>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const void* kern;
+    constexpr bool kPlain = T == 1 && MODE == 0;  // the one-tile kernel without a mask stage
+    if constexpr (kPlain) kern = reinterpret_cast<const void*>(forward_bf16_kernel<KS0, kWaves>);
+    else kern = reinterpret_cast<const void*>(forward_bf16_tiles_kernel<KS0, kWaves, T, MODE>);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_bf16, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
     // Row superblock: large enough that staging 89 KB of weights is ~1 % of its MFMA time
     // (64 tiles per wave at 8 waves), small enough that pairs x superblocks >> 256 CUs.
     const int64_t padded = rows_pad(n_rows);
     const int step = 32 * kWaves * T;
-    int rows_per_block = 16384 / step * step;
+#ifndef MCMC_ROWS_PER_BLOCK
+#define MCMC_ROWS_PER_BLOCK 16384
+#endif
+    int rows_per_block = MCMC_ROWS_PER_BLOCK / step * step;
     if (padded < rows_per_block) rows_per_block = (int)((padded + step - 1) / step * step);
     const int64_t row_blocks = (padded + rows_per_block - 1) / rows_per_block;
     if (row_blocks > 65535) return set_error(MCMC_EINVAL, "n_rows too large for one launch (%lld row blocks)", (long long)row_blocks);
     for (int done = 0; done < pair_count;) {
         const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
-        hipLaunchKernelGGL(kern, dim3(n, (unsigned)row_blocks), dim3(64 * kWaves), lds_bytes, s, (const unsigned short*)xpack, n_rows,
-                           F, rows_per_block, (const unsigned char*)wpack + (int64_t)done * L.total, Y + (int64_t)done * ldY, ldY);
+        const unsigned char* wp = (const unsigned char*)wpack + (int64_t)done * L.total;
+        float* y = Y + (int64_t)done * ldY;
+        if constexpr (kPlain) {
+            hipLaunchKernelGGL((forward_bf16_kernel<KS0, kWaves>), dim3(n, (unsigned)row_blocks), dim3(64 * kWaves), lds_bytes, s,
+                               (const unsigned short*)xpack, n_rows, F, rows_per_block, wp, y, ldY);
+        } else {
+            DropMask d = dm;  // this slab's pairs: host masks and the pair ids advance with it
+            if (MODE == 1) {
+                d.m[0] += (int64_t)done * n_rows * H1;
+                d.m[1] += (int64_t)done * n_rows * H2;
+                d.m[2] += (int64_t)done * n_rows * H3;
+            }
+            d.pair_begin += done;
+            hipLaunchKernelGGL((forward_bf16_tiles_kernel<KS0, kWaves, T, MODE>), dim3(n, (unsigned)row_blocks), dim3(64 * kWaves),
+                               lds_bytes, s, (const unsigned short*)xpack, n_rows, F, rows_per_block, wp, y, ldY, d);
+        }
         done += n;
     }
     return check_launch("forward_bf16");
@@ -304,8 +342,17 @@ static int launch_variant(const void* xpack, int64_t n_rows, int F, const void* 
 }  // namespace
 
 int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
-                        float* Y, int64_t ldY, hipStream_t s) {
+                        const DropMask* dm, float* Y, int64_t ldY, hipStream_t s) {
     (void)ctx;
+    if (dm && dm->mode) {  // train-mode dropout: the two-tile kernel with the mask stage compiled in
+        const bool k16 = WPackBF16(F).K0 == 16;
+        if (dm->mode == 1) {
+            if (k16) return launch_variant<1, 8, 2, 1>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s, *dm);
+            return launch_variant<2, 8, 2, 1>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s, *dm);
+        }
+        if (k16) return launch_variant<1, 8, 2, 2>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s, *dm);
+        return launch_variant<2, 8, 2, 2>(xpack, n_rows, F, wpack, pair_count, Y, ldY, s, *dm);
+    }
     static const int waves = [] {
         const char* e = getenv("MCMC_FWD_WAVES");  // tuning knob; default chosen by measurement
         const int w = e ? atoi(e) : kDefaultWaves;

@@ -11,6 +11,7 @@
 // (L0+L1+b1 = 141 KB, then L2+b2+w3+b3 = 33 KB) because fp32 weights (177 KB) exceed the CU's
 // 160 KB.  Dropout keep-masks (train mode) are applied in the activation epilogue.
 #include "common.hpp"
+#include "dropmask.hpp"
 
 namespace mcmc {
 
@@ -29,11 +30,10 @@ __device__ __forceinline__ void stage(float* lds, const float* __restrict__ src,
 constexpr int kWavesF32 = 8;                 // waves per workgroup
 constexpr int kRowsF32 = 32 * kWavesF32;    // rows per workgroup
 
-template <bool MASKED>
+template <int MODE>
 __global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const float* __restrict__ xpack, int64_t n_rows, int F,
-                                                             const float* __restrict__ wpack, const uint8_t* __restrict__ m0,
-                                                             const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
-                                                             float keep_scale, float* __restrict__ Y, int64_t ldY) {
+                                                             const float* __restrict__ wpack, DropMask dm,
+                                                             float* __restrict__ Y, int64_t ldY) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const WPackF32 L(F);
     const int ks0 = L.K0 / 2;
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const fl
     const int64_t row = row0 + r;
     const bool active = row0 < rows_pad(n_rows);  // wave-uniform
     const bool real_row = row < n_rows;
+    const uint32_t g = MODE == 2 ? drop_pair_id(dm, c) : 0u;
 
     stage(lds, wp, L.l2);  // L0, L1, B1
     __syncthreads();
@@ -62,15 +63,12 @@ __global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const fl
 #pragma unroll
             for (int i = 0; i < kMaxInputDim / 2 + 1; ++i)
                 if (i < ks0) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L.l0 + (mo * ks0 + i) * 64 + lane], xv[i], acc, 0, 0, 0);
+            float o[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = elu1(acc[i]);
-                if (MASKED && real_row) {
-                    const int feat = 32 * mo + acc_feature(i, h);
-                    v = v * (float)m0[((int64_t)c * n_rows + row) * H1 + feat] * keep_scale;
-                }
-                h1[mo][i] = v;
-            }
+            for (int i = 0; i < 16; ++i) o[i] = elu1(acc[i]);
+            drop16<MODE>(o, dm, 0, mo, h, c, g, n_rows, row);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h1[mo][i] = o[i];
         }
         // ---- layer 1: 128 k-steps per 32-feature output tile ----
 #pragma unroll
@@ -84,15 +82,12 @@ __global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const fl
             for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(mt * 16 + i) * 64], h1[mt][i], acc, 0, 0, 0);
+            float o[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = elu1(acc[i]);
-                if (MASKED && real_row) {
-                    const int feat = 32 * mo + acc_feature(i, h);
-                    v = v * (float)m1[((int64_t)c * n_rows + row) * H2 + feat] * keep_scale;
-                }
-                h2[mo][i] = v;
-            }
+            for (int i = 0; i < 16; ++i) o[i] = elu1(acc[i]);
+            drop16<MODE>(o, dm, 1, mo, h, c, g, n_rows, row);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) h2[mo][i] = o[i];
         }
     }
     __syncthreads();
@@ -114,15 +109,12 @@ __global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const fl
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(mt * 16 + i) * 64], h2[mt][i], acc, 0, 0, 0);
         const float* w3 = lds + o_w3 + (mo * 2 + h) * 16;
+        float o[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float v = elu1(acc[i]);
-            if (MASKED && real_row) {
-                const int feat = 32 * mo + acc_feature(i, h);
-                v = v * (float)m2[((int64_t)c * n_rows + row) * H3 + feat] * keep_scale;
-            }
-            y = fmaf(w3[i], v, y);
-        }
+        for (int i = 0; i < 16; ++i) o[i] = elu1(acc[i]);
+        drop16<MODE>(o, dm, 2, mo, h, c, g, n_rows, row);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y = fmaf(w3[i], o[i], y);
     }
     y += __shfl_xor(y, 32);
     y += lds[o_b3];
@@ -131,22 +123,26 @@ __global__ __launch_bounds__(64 * kWavesF32, 1) void forward_f32_kernel(const fl
 
 }  // namespace
 
-int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count, const uint8_t* m0,
-                       const uint8_t* m1, const uint8_t* m2, float keep_scale, float* Y, int64_t ldY, hipStream_t s) {
+int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count, const DropMask* dmp, float* Y,
+                       int64_t ldY, hipStream_t s) {
     const WPackF32 L(F);
     const size_t lds_bytes = (size_t)L.l2 * sizeof(float);
-    const bool masked = m0 != nullptr;
-    auto kern = masked ? forward_f32_kernel<true> : forward_f32_kernel<false>;
+    const DropMask dm = dmp ? *dmp : DropMask{};
+    auto kern = dm.mode == 1 ? forward_f32_kernel<1> : dm.mode == 2 ? forward_f32_kernel<2> : forward_f32_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_f32, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
     const int64_t row_blocks = (rows_pad(n_rows) + kRowsF32 - 1) / kRowsF32;
     for (int done = 0; done < pair_count;) {
         const int n = pair_count - done > 32768 ? 32768 : pair_count - done;
-        const int64_t mask_pair = n_rows;  // masks advance by n_rows * width per pair
+        DropMask d = dm;  // this slab's pairs: host masks and the pair ids advance with it
+        if (dm.mode == 1) {
+            d.m[0] += (int64_t)done * n_rows * H1;
+            d.m[1] += (int64_t)done * n_rows * H2;
+            d.m[2] += (int64_t)done * n_rows * H3;
+        }
+        d.pair_begin += done;
         hipLaunchKernelGGL(kern, dim3((unsigned)row_blocks, n), dim3(64 * kWavesF32), lds_bytes, s, xpack, n_rows, F,
-                           wpack + (int64_t)done * L.total, masked ? m0 + (int64_t)done * mask_pair * H1 : nullptr,
-                           masked ? m1 + (int64_t)done * mask_pair * H2 : nullptr,
-                           masked ? m2 + (int64_t)done * mask_pair * H3 : nullptr, keep_scale, Y + (int64_t)done * ldY, ldY);
+                           wpack + (int64_t)done * L.total, d, Y + (int64_t)done * ldY, ldY);
         done += n;
     }
     return check_launch("forward_f32");

@@ -250,7 +250,15 @@ class Engine:
         return eps
 
     def forward(self, dtype: int, xpack, B: int, F: int, wpack, pair_count: int, Y: torch.Tensor, ldY: int,
-                masks=None, keep_scale: float = 1.0):
+                masks=None, keep_scale: float = 1.0, philox_dropout: Optional[Tuple[int, float, int, int, int]] = None):
+        """masks: three host keep-masks [pair_count, B, 256/128/64] uint8 (train-mode forward);
+        philox_dropout: (mask_seed, p_drop, n_members, n_samples, pair_begin) for counter-based masks."""
+        if philox_dropout is not None:
+            mseed, p_drop, M, S, pair_begin = philox_dropout
+            _lib.check(self.lib.mcmc_forward_dropout(self.ctx.handle, dtype, _p(xpack), B, F, _p(wpack), M, S, pair_begin, pair_count,
+                                                     mseed & 0xFFFFFFFFFFFFFFFF, float(p_drop), _p(Y), ldY, _stream()),
+                       "mcmc_forward_dropout")
+            return
         m0 = m1 = m2 = None
         if masks is not None:
             m0, m1, m2 = masks
@@ -337,7 +345,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
                q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
                chunk_pairs: Optional[int] = None, group=None, return_samples: bool = False,
-               timers: Optional[dict] = None) -> PredictResult:
+               timers: Optional[dict] = None, mc_dropout: bool = False, p_drop: float = 0.1,
+               mask_seed: Optional[int] = None) -> PredictResult:
     """Monte Carlo predictive statistics of the ensemble over X.
 
     X [B,F] fp32 on a HIP device; mu, rho [M,P] fp32 (pack_members).  noise: 'philox'
@@ -348,6 +357,9 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     rank finalizes its row slice, and the results are all-gathered: every rank returns the full
     result.  ``timers``: optional dict; per kernel name it collects
     (start, end) torch.cuda.Event pairs recorded on the launch stream around each launch.
+    ``mc_dropout`` (extension; the reference's predict() runs in eval mode, bayesian_ensemble.py:215-216):
+    keep the members' Dropout(p_drop) live, with counter-based Philox masks keyed by (mask_seed or seed;
+    global pair id, row, element) applied inside the MFMA kernels' activation stage.
     """
     import torch.distributed as dist
     dev_index = _require_gpu(X, "X")
@@ -400,7 +412,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
             with _timed(timers, "sample_weights"):
                 eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
             with _timed(timers, "forward", cnt):
-                eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY)
+                eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY,
+                            philox_dropout=(seed if mask_seed is None else mask_seed, p_drop, M, S, begin) if mc_dropout else None)
             if nq and first:
                 # pilot: the first chunk's moments (all ranks') place every row's histogram
                 pilot = eng.new_state(B)

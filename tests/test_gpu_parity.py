@@ -430,3 +430,67 @@ def test_predict_plan_graph_replay_equals_eager(golden, dtype):
     assert torch.equal(plan(X2, mu, rho, 3).mean, mc_predict(X2, mu, rho, S, dtype=dtype, seed=3, q_levels=Q).mean)
     with pytest.raises(ValueError):
         plan(X[:100], mu, rho, 1)
+
+
+def _philox_masks(seed, pair_ids, rows):
+    """Keep-masks [pairs, rows, 256/128/64] from the oracle's restatement of the 'MASK' Philox stream."""
+    per = [orc.philox_keep_masks(seed, int(g), rows) for g in pair_ids]
+    return [np.stack([p[l] for p in per]) for l in range(3)]
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+def test_mc_dropout_philox_masks_match_oracle(golden, dtype, tol):
+    """Counter-based dropout masks inside the MFMA forward (north-star piece 1): the samples equal the oracle's
+    train-mode forward fed with the oracle's restatement of the same Philox mask stream; chunking does not matter."""
+    from mcmc_amd import mc_predict
+    g = golden("predict_small.npz")
+    d = _dev()
+    X, mu, rho, eps = (torch.from_numpy(g[k]) for k in ("X", "mu", "rho", "eps"))
+    M, S, P = eps.shape
+    B = X.shape[0]
+    seed = 0xC0FFEE1234
+    kw = dict(dtype=dtype, noise="injected", eps=eps.reshape(M * S, P).to(d), return_samples=True, mc_dropout=True, mask_seed=seed)
+    res = mc_predict(X.to(d), mu.to(d), rho.to(d), S, **kw)
+    masks = _philox_masks(seed, range(M * S), B)
+    ref = torch.stack([orc.forward_pair(X, mu[p // S], rho[p // S], eps[p // S, p % S],
+                                        masks=[torch.from_numpy(m[p]) for m in masks]) for p in range(M * S)])
+    err = float((res.samples.cpu() - ref).abs().max())
+    assert err <= tol * max(1.0, float(ref.abs().max())), (dtype, err)
+    plain = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype=dtype, noise="injected", eps=eps.reshape(M * S, P).to(d), return_samples=True)
+    assert float((plain.samples - res.samples).abs().max()) > 1e-3  # the masks did something
+    chunked = mc_predict(X.to(d), mu.to(d), rho.to(d), S, chunk_pairs=5, **kw)
+    assert torch.equal(chunked.samples, res.samples)
+
+
+def test_bf16_host_masks_equal_philox_masks(golden):
+    """bf16 MFMA forward: masks supplied from the host give bit-for-bit what the in-kernel Philox masks give
+    when the host masks are that same stream (and match the fp32 oracle within the bf16 bar)."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import Engine
+    g = golden("train_fwd.npz")
+    d = _dev()
+    eng = Engine(d)
+    X = torch.from_numpy(g["X"]).to(d)
+    B, F = X.shape
+    npass = g["eps"].shape[0]
+    mu, rho = torch.from_numpy(g["mu"]).to(d), torch.from_numpy(g["rho"]).to(d)
+    eps = torch.from_numpy(g["eps"]).to(d)  # M = 1, S = npass
+    seed, ldY = 77, 64
+    for dt in (_lib.DT_BF16, _lib.DT_F32):
+        xp = eng.pack_x(X, dt)
+        wp = torch.empty(npass * eng.wpack_bytes(F, dt), dtype=torch.uint8, device=d)
+        eng.sample_weights(mu, rho, npass, F, 0, npass, _lib.NOISE_INJECTED, eps, 0, dt, wp)
+        Yp, Yh = torch.zeros(npass, ldY, device=d), torch.zeros(npass, ldY, device=d)
+        eng.forward(dt, xp, B, F, wp, npass, Yp, ldY, philox_dropout=(seed, 0.1, 1, npass, 0))
+        hm = [torch.from_numpy(m).to(d).contiguous() for m in _philox_masks(seed, range(npass), B)]
+        eng.forward(dt, xp, B, F, wp, npass, Yh, ldY, masks=hm, keep_scale=float(torch.tensor(1.0 / 0.9, dtype=torch.float32)))
+        assert torch.equal(Yp, Yh)
+    # the reference's own recorded masks through the bf16 kernel
+    masks = [torch.from_numpy(g[f"mask{l}"]).to(d).contiguous() for l in range(3)]
+    xp = eng.pack_x(X, _lib.DT_BF16)
+    wp = torch.empty(npass * eng.wpack_bytes(F, _lib.DT_BF16), dtype=torch.uint8, device=d)
+    eng.sample_weights(mu, rho, npass, F, 0, npass, _lib.NOISE_INJECTED, eps, 0, _lib.DT_BF16, wp)
+    Y = torch.zeros(npass, ldY, device=d)
+    eng.forward(_lib.DT_BF16, xp, B, F, wp, npass, Y, ldY, masks=masks, keep_scale=float(torch.tensor(1.0 / 0.9, dtype=torch.float32)))
+    got = Y[:, :B].cpu().numpy()
+    assert np.max(np.abs(got - g["out"])) <= 2e-2 * max(1.0, np.max(np.abs(g["out"])))

@@ -50,12 +50,12 @@ int main(int argc, char** argv) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, dy, ldY, 0)) return 1;
+    if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int i = 0; i < iters; ++i) {
         CK(hipEventRecord(a, 0));
-        if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, dy, ldY, 0)) return 1;
+        if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms;
