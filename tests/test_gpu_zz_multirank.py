@@ -2,8 +2,8 @@
 multi-rank host logic: pair-sharded predict with the reduce-scatter exchange, the data-parallel loss and
 the data-parallel training step, each compared with a single-rank run (tools/check_multirank.py).
 
-The file sorts before the other GPU tests on purpose: the ranks are child processes, started before this
-process has touched the GPU."""
+The ranks are child processes of the test (never an exec of this process).  The file sorts after the other
+GPU tests on purpose: the round-end run uses pytest -x, and a failure here must not hide them."""
 import os
 import socket
 import subprocess
