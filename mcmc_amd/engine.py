@@ -329,6 +329,17 @@ class PredictResult:
     n_samples: int = 0
 
 
+PILOT_PAIRS = 128
+
+
+def pilot_pairs(cnt: int, M: int) -> int:
+    """Pairs of the first chunk whose moments place the histogram (whole rounds of members, ~128 per rank):
+    the range is mean +- range_sigmas * std with catch-all end bins, so a 6 % error of the pilot's std moves
+    the edges by a fraction of a sigma; reducing the whole first chunk twice would cost a full extra pass."""
+    want = max(M, PILOT_PAIRS // M * M)
+    return min(cnt, want)
+
+
 def default_chunk_pairs(ldY: int, wpack_bytes: int, M: int, device) -> int:
     """Pairs per chunk: the sample buffer Y[C, ldY] fp32 plus the chunk's packed weights within
     min(16 GiB, a quarter of free HBM).  MI355X has 288 GB: large chunks keep the histogram's
@@ -417,7 +428,7 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
             if nq and first:
                 # pilot: the first chunk's moments (all ranks') place every row's histogram
                 pilot = eng.new_state(B)
-                eng.reduce_update(Y, ldY, cnt, B, pilot)
+                eng.reduce_update(Y, ldY, pilot_pairs(cnt, M), B, pilot)
                 pilot = combine_partials(pilot, group)
                 eng.set_edges(B, pilot.n, pilot.sum, pilot.sumsq, st, range_sigmas)
             first = False
@@ -487,7 +498,7 @@ class PredictPlan:
         st.n = pilot.n = 0
         if self.q_levels:
             st.hist.zero_()
-            eng.reduce_update(self.Y, self.ldY, self.N, self.B, pilot)
+            eng.reduce_update(self.Y, self.ldY, pilot_pairs(self.N, self.M), self.B, pilot)
             eng.set_edges(self.B, pilot.n, pilot.sum, pilot.sumsq, st, self.range_sigmas)
         eng.reduce_update(self.Y, self.ldY, self.N, self.B, st)
         mean, std, quant = eng.finalize(self.B, st, self.q_levels)
