@@ -150,6 +150,9 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
     }
 
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 2)
+    float f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
+#endif
     const f32x4* yp = reinterpret_cast<const f32x4*>(Y + row0);
     const int64_t ld4 = ldY >> 2;
     // Histogram address arithmetic, 9 VALU instructions per sample: with u = bin + 4*rq (the row
@@ -161,9 +164,14 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
         const float v[4] = {q[0], q[1], q[2], q[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 2)
+            f1[j] += v[j];
+            f2[j] = fmaf(v[j], v[j], f2[j]);
+#else
             const double d = (double)v[j];
             s1[j] += d;
             s2[j] = fma(d, d, s2[j]);
+#endif
             if (HIST && (!decltype(tail)::value || row0 + j < n_rows)) {
                 // same arithmetic as hist_bin(): two roundings, clamp to [-1, nbins-2] (NaN -> -1), floor
                 const float t = __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[j], lo[j]), inv_w[j]), -1.0f, hi_clamp);
@@ -171,7 +179,13 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
                 asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(bm1) : "v"(t));
                 const unsigned u = (unsigned)(bm1 + 1 + 4 * rq);
                 const unsigned word = __builtin_amdgcn_ubfe(u, 1, lw);
+#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 1)
+                uint32_t* ap = &lh[(4 * rq + j) * words + word];
+                const unsigned av = (u & 1u) * 65535u + 1u;
+                asm volatile("" ::"v"(ap), "v"(av));
+#else
                 atomicAdd(&lh[(4 * rq + j) * words + word], (u & 1u) * 65535u + 1u);
+#endif
             }
         }
     };
@@ -196,6 +210,9 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
             for (int c = slot; c < n_pairs; c += kSlots) consume(__builtin_nontemporal_load(yp + (int64_t)c * ld4), yes{});
         }
     }
+#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 2)
+    for (int j = 0; j < 4; ++j) { s1[j] = f1[j]; s2[j] = f2[j]; }
+#endif
     // the 4 pair-slots of a wave sit 16 lanes apart: fold them, then the waves through LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -342,10 +342,11 @@ def pilot_pairs(cnt: int, M: int) -> int:
 
 def default_chunk_pairs(ldY: int, wpack_bytes: int, M: int, device) -> int:
     """Pairs per chunk: the sample buffer Y[C, ldY] fp32 plus the chunk's packed weights within
-    min(16 GiB, a quarter of free HBM).  MI355X has 288 GB: large chunks keep the histogram's
-    read-modify-write small beside the sample stream."""
+    min(32 GiB, a quarter of free HBM).  MI355X has 288 GB: large chunks keep the histogram's
+    per-chunk state pass (read-modify-write of 2*nbins bytes per row plus the workgroups' prologue
+    and flush phases, ~0.7 ms at 3.65 M rows) small beside the sample stream."""
     free, _ = torch.cuda.mem_get_info(device)
-    budget = min(16 << 30, free // 4)
+    budget = min(32 << 30, free // 4)
     c = max(1, budget // (ldY * 4 + wpack_bytes))
     if c > M:
         c -= c % M  # whole rounds of members per chunk
