@@ -180,7 +180,7 @@ def main():
                          "traffic": load_traffic(fwd_units / max(len(fwd_ms), 1)),
                          "launches": len(fwd_ms), "avg_launch_ms": (sum(fwd_ms) / len(fwd_ms)) if fwd_ms else None,
                          "flop_per_unit": FLOP_PER_UNIT},
-            "reduce": {"bound": "hbm", "kernel": "reduce_update_kernel",
+            "reduce": {"bound": "hbm", "kernel": "reduce_update4_kernel",
                        "achieved_GBps": (red_units * 4 / red_s / 1e9) if red_s > 0 else None, "peak_GBps": PEAK_HBM / 1e9,
                        "note": "sample bytes only (4 B/unit), launches inside the timed steps"},
         }
