@@ -56,7 +56,7 @@ __device__ __forceinline__ void drop16(float (&o)[16], const DropMask& dm, int l
             keep[3] = u01(x.w) < dm.keep_prob;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[4 * q + j] = keep[j] ? o[4 * q + j] * dm.scale : 0.0f;
+        for (int j = 0; j < 4; ++j) o[4 * q + j] = keep[j] ? o[4 * q + j] * dm.scale : -0.0f;  // -0: zero, and marks "dropped" for train.hip's backward
     }
 }
 

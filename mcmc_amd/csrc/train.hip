@@ -8,104 +8,77 @@
 //   backward through the reparameterisation (dmu = dW, drho = dW * eps * exp(rho)),
 //   clip_grad_norm_(1.0) (:179), AdamW step (:180; lr / beta1 come from the host's OneCycleLR).
 //
-// The batch is 32 rows (:124), so every GEMM here is tiny: the step is launch- and latency-bound,
-// not MFMA-bound.  One workgroup owns one (member, sample) pair and keeps all activations of a
-// 32-row tile in LDS (141 KB); weights stream from L2 in two pre-sampled layouts (W [out][in] for
-// the input gradients, WT [in][out] for the forward) so every global access is lane-contiguous.
-// fp32 VALU arithmetic throughout - this path is about fidelity and launch count, not FLOP/s.
+// The batch is 32 rows (:124), so every GEMM here is one or a few 32x32 MFMA tiles.  One workgroup (4 waves)
+// owns one (member, sample) pair and keeps the activations and their gradients of a 32-row tile in LDS
+// ([row][feature] tiles with odd strides, 120 KB); the weights stream from L2 in two pre-sampled layouts
+// (WT [in][out] for the forward, W [out][in] for the input gradients) as MFMA A operands, 32 consecutive
+// floats per lane half.  All GEMMs run on v_mfma_f32_32x32x2_f32: exact fp32 FMAs, so the step stays
+// within 2e-5 of the reference's fp32 autograd.
 #include "common.hpp"
-#include "philox.hpp"
+#include "dropmask.hpp"
 
 namespace mcmc {
 
 namespace {
 
 constexpr int TR = 32;         // rows per LDS tile
-constexpr int NT = 256;        // threads per workgroup
-constexpr int XS = 28;         // LDS row stride of the input tile (>= kMaxInputDim, multiple of 4)
+constexpr int NT = 256;        // threads per workgroup (4 waves)
+constexpr int NW = NT / 64;
+// LDS row strides of the [row][feature] tiles: odd, so a column read (32 rows of one feature: the MFMA's B
+// operand) and a row read (32 consecutive features: its A operand) are both bank-conflict-free
+constexpr int SX = 33, S1 = H1 + 1, S2 = H2 + 1, S3 = H3 + 1;
 
-struct MaskSrc {
-    const uint8_t* m0;  // host-supplied keep masks [pairs, rows, 256/128/64] or null
-    const uint8_t* m1;
-    const uint8_t* m2;
-    uint64_t seed;      // Philox mask key
-    int mode;           // 0 none, 1 host, 2 philox
-    float keep_prob;    // 1 - p
-    float scale;        // fp32(1/(1-p)), torch's dropout scale
-};
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// keep flag of activation element `feat` (0..447 over the three hidden layers) of (pair, row)
-__device__ __forceinline__ bool keep_flag(const MaskSrc& ms, int pair, int64_t rows, int64_t row, int layer, int feat) {
-    if (ms.mode == 0) return true;
-    if (ms.mode == 1) {
-        const uint8_t* m = layer == 0 ? ms.m0 : layer == 1 ? ms.m1 : ms.m2;
-        const int width = layer == 0 ? H1 : layer == 1 ? H2 : H3;
-        return m[((int64_t)pair * rows + row) * width + feat] != 0;
-    }
-    const int elem = (layer == 0 ? 0 : layer == 1 ? H1 : H1 + H2) + feat;
-    // torch: mask = bernoulli(1-p), i.e. keep with probability keep_prob
-    return philox_mask_uniform(ms.seed, (uint32_t)pair, (uint32_t)row, (uint32_t)elem) < ms.keep_prob;
-}
+// One k-step of v_mfma_f32_32x32x2_f32 (exact fp32 FMAs): D[32 x 32] += A[32 x 2] * B[2 x 32]; lane (r, h) feeds
+// A[r][h] and B[h][r]; afterwards register i of lane (r, h) holds D[acc_feature(i, h)][r] (layout.hpp).
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
 
-// ---- dense layers on LDS tiles --------------------------------------------------------------
-// z[r][o] = b[o] + sum_k hin[r][k] * WT[k][o];  then h = elu(z) * mask * scale stored in place.
-// Masked elements are stored as -0.0f: arithmetic zero, and recognisable in the backward pass.
-template <int IN, int OUT, int IN_STRIDE>
-__device__ __forceinline__ void dense_forward(const float* __restrict__ hin, const float* __restrict__ WT,
-                                              const float* __restrict__ bias, float* __restrict__ hout, const MaskSrc& ms,
-                                              int pair, int64_t rows, int64_t row_base, int layer) {
-    constexpr int G = NT / OUT, RG = TR / G;  // row groups, rows per thread
-    const int o = threadIdx.x % OUT, g = threadIdx.x / OUT;
-    float acc[RG];
-    const float b = bias[o];
+// ---- dense layers on LDS tiles, MFMA ---------------------------------------------------------------
+// Z^T[out, row] = b[out] + sum_k WT[k][out] * hin[row][k]; then h = elu(z) * mask * scale -> hout[row][out].
+// A comes straight from the pre-sampled WT image in global memory / L2 (32 consecutive floats per lane half),
+// B from the LDS tile.  Wave w owns output tiles w, w+4, ...  Masked elements and padding rows are stored as
+// -0.0f: arithmetic zero, and recognisable in the backward pass.
+template <int MODE, int OUT, int IN_STRIDE, int OUT_STRIDE>
+__device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int K, const float* __restrict__ WT,
+                                              const float* __restrict__ bias, float* __restrict__ hout, const DropMask& dm, int pair,
+                                              int64_t rows, int64_t row_base, int layer) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const bool live = row_base + r < rows;
+    for (int mo = wave; mo < OUT / 32; mo += NW) {
+        f32x16 acc;
 #pragma unroll
-    for (int rr = 0; rr < RG; ++rr) acc[rr] = b;
-    if constexpr (IN % 4 == 0) {
-        for (int k = 0; k < IN; k += 4) {
-            const float w0 = WT[(k + 0) * OUT + o], w1 = WT[(k + 1) * OUT + o], w2 = WT[(k + 2) * OUT + o], w3 = WT[(k + 3) * OUT + o];
+        for (int i = 0; i < 16; ++i) acc[i] = bias[32 * mo + acc_feature(i, h)];
+        const float* a = WT + 32 * mo + r;
+        const float* b = hin + r * IN_STRIDE;
+        // every weight is used once per tile, so the A stream is bound by L2 latency: issue a batch of loads,
+        // then the MFMAs that consume them
+        if (K % 32) {  // layer 0: K = input width (<= kMaxInputDim), possibly odd; xs columns >= K are zero
+            float av[(kMaxInputDim + 1) / 2], bv[(kMaxInputDim + 1) / 2];
 #pragma unroll
-            for (int rr = 0; rr < RG; ++rr) {
-                const float4 h = *reinterpret_cast<const float4*>(hin + (g * RG + rr) * IN_STRIDE + k);
-                acc[rr] = fmaf(h.x, w0, acc[rr]);
-                acc[rr] = fmaf(h.y, w1, acc[rr]);
-                acc[rr] = fmaf(h.z, w2, acc[rr]);
-                acc[rr] = fmaf(h.w, w3, acc[rr]);
+            for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st) {
+                const int k = 2 * st + h;
+                av[st] = k < K ? a[k * OUT] : 0.0f;
+                bv[st] = b[k];
+            }
+#pragma unroll
+            for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st)
+                if (2 * st < K) acc = mfma2(av[st], bv[st], acc);
+        } else {
+            for (int s0 = 0; s0 < K / 2; s0 += 32) {
+                float av[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) av[u] = a[(2 * (s0 + u) + h) * OUT];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc = mfma2(av[u], b[2 * (s0 + u) + h], acc);
             }
         }
-    }
+        float o[16];
 #pragma unroll
-    for (int rr = 0; rr < RG; ++rr) {
-        const int r = g * RG + rr;
-        const float z = acc[rr];
-        float h = z > 0.0f ? z : expm1f(z);
-        const bool live = row_base + r < rows;
-        if (ms.mode != 0) h = (live && keep_flag(ms, pair, rows, row_base + r, layer, o)) ? h * ms.scale : -0.0f;
-        hout[r * OUT + o] = live ? h : -0.0f;
-    }
-}
-
-// layer 0: the input width is a runtime value (7..24), scalar k loop
-template <int OUT>
-__device__ __forceinline__ void dense_forward_in(const float* __restrict__ xs, int F, const float* __restrict__ WT,
-                                                 const float* __restrict__ bias, float* __restrict__ hout, const MaskSrc& ms, int pair,
-                                                 int64_t rows, int64_t row_base) {
-    const int o = threadIdx.x;  // OUT == NT == 256
-    float acc[TR];
-    const float b = bias[o];
+        for (int i = 0; i < 16; ++i) o[i] = acc[i] > 0.0f ? acc[i] : expm1f(acc[i]);
+        drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row_base + r);
 #pragma unroll
-    for (int r = 0; r < TR; ++r) acc[r] = b;
-    for (int k = 0; k < F; ++k) {
-        const float w = WT[k * OUT + o];
-#pragma unroll
-        for (int r = 0; r < TR; ++r) acc[r] = fmaf(xs[r * XS + k], w, acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        const float z = acc[r];
-        float h = z > 0.0f ? z : expm1f(z);
-        const bool live = row_base + r < rows;
-        if (ms.mode != 0) h = (live && keep_flag(ms, pair, rows, row_base + r, 0, o)) ? h * ms.scale : -0.0f;
-        hout[r * OUT + o] = live ? h : -0.0f;
+        for (int i = 0; i < 16; ++i) hout[r * OUT_STRIDE + 32 * mo + acc_feature(i, h)] = live ? o[i] : -0.0f;
     }
 }
 
@@ -115,52 +88,113 @@ __device__ __forceinline__ float dfactor(float h, float scale) {
     return h > 0.0f ? scale : h + scale;                 // z > 0: scale;  z <= 0: exp(z)*scale = h + scale
 }
 
+// dW[out][in] (+)= sum_r dz[r][out] * hin[r][in] for one 32-row tile: both operands are row reads of LDS tiles.
+template <int OUT, int DZ_STRIDE, int IN_STRIDE>
+__device__ __forceinline__ void weight_grad(const float* __restrict__ dz, const float* __restrict__ hin, int IN, float* __restrict__ g,
+                                            bool first) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int n_in = (IN + 31) / 32;
+    for (int tile = wave; tile < (OUT / 32) * n_in; tile += NW) {
+        const int mo = tile / n_in, ni = tile % n_in;
+        f32x16 acc = {0};
+        const float* a = dz + 32 * mo + r;
+        const float* b = hin + 32 * ni + r;
+#pragma unroll
+        for (int k = 0; k < TR; k += 2) acc = mfma2(a[(k + h) * DZ_STRIDE], b[(k + h) * IN_STRIDE], acc);
+        const int in = 32 * ni + r;
+        if (in < IN) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float* p = g + (int64_t)(32 * mo + acc_feature(i, h)) * IN + in;
+                *p = first ? acc[i] : *p + acc[i];
+            }
+        }
+    }
+}
+
+// db[o] (+)= sum_r dz[r][o]
+template <int OUT, int DZ_STRIDE>
+__device__ __forceinline__ void bias_grad(const float* __restrict__ dz, float* __restrict__ g, bool first) {
+    for (int o = threadIdx.x; o < OUT; o += NT) {
+        float a = 0.0f;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) a += dz[r * DZ_STRIDE + o];
+        g[o] = first ? a : g[o] + a;
+    }
+}
+
+// dzin[r][in] = (sum_o dz[r][o] * W[o][in]) * d(hin[r][in]): A = rows of W [out][in] from global memory / L2,
+// B = columns of the dz tile.
+template <int OUT, int IN, int DZ_STRIDE, int IN_STRIDE>
+__device__ __forceinline__ void input_grad(const float* __restrict__ dz, const float* __restrict__ W, const float* __restrict__ hin,
+                                           float scale, float* __restrict__ dzin) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    for (int mi = wave; mi < IN / 32; mi += NW) {
+        f32x16 acc = {0};
+        const float* a = W + 32 * mi + r;
+        const float* b = dz + r * DZ_STRIDE;
+        for (int s0 = 0; s0 < OUT / 2; s0 += 32) {
+            float av[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) av[u] = a[(2 * (s0 + u) + h) * IN];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc = mfma2(av[u], b[2 * (s0 + u) + h], acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int in = 32 * mi + acc_feature(i, h);
+            dzin[r * IN_STRIDE + in] = acc[i] * dfactor(hin[r * IN_STRIDE + in], scale);
+        }
+    }
+}
+
 struct Lds {
-    float* xs;   // [TR][XS]
-    float* h1;   // [TR][256]
-    float* h2;   // [TR][128]
-    float* h3;   // [TR][64]
-    float* ga;   // gradient scratch A: [TR][256]
-    float* gb;   // gradient scratch B: [TR][128] + transposed [128][TR]
-    float* gc;   // gradient scratch C: [TR][64] + transposed [64][TR]
-    float* y;    // [TR]
+    float* xs;   // [TR][SX]  input tile, columns >= F are zero
+    float* h1;   // [TR][S1]
+    float* h2;   // [TR][S2]
+    float* h3;   // [TR][S3]
+    float* d1;   // dz0 [TR][S1]
+    float* d2;   // dz1 [TR][S2]
+    float* d3;   // dz2 [TR][S3]
+    float* y;    // [TR] outputs, then dLoss/dy in the backward pass
 };
-constexpr int kLdsFloats = TR * XS + TR * (H1 + H2 + H3) + TR * H1 + 2 * TR * H2 + 2 * TR * H3 + TR;
+constexpr int kLdsFloats = TR * (SX + 2 * (S1 + S2 + S3) + 1);
 
 __device__ __forceinline__ Lds carve(float* base) {
     Lds l;
     l.xs = base;
-    l.h1 = l.xs + TR * XS;
-    l.h2 = l.h1 + TR * H1;
-    l.h3 = l.h2 + TR * H2;
-    l.ga = l.h3 + TR * H3;
-    l.gb = l.ga + TR * H1;
-    l.gc = l.gb + 2 * TR * H2;
-    l.y = l.gc + 2 * TR * H3;
+    l.h1 = l.xs + TR * SX;
+    l.h2 = l.h1 + TR * S1;
+    l.h3 = l.h2 + TR * S2;
+    l.d1 = l.h3 + TR * S3;
+    l.d2 = l.d1 + TR * S1;
+    l.d3 = l.d2 + TR * S2;
+    l.y = l.d3 + TR * S3;
     return l;
 }
 
 // forward of one 32-row tile of one pair; fills xs, h1, h2, h3, y
+template <int MODE>
 __device__ __forceinline__ void forward_tile(const Lds& l, const float* __restrict__ xb, int64_t rows, int F, int64_t row_base,
-                                             const float* __restrict__ WT, const MaskSrc& ms, int pair) {
-    for (int i = threadIdx.x; i < TR * XS; i += NT) {
-        const int r = i / XS, k = i % XS;
+                                             const float* __restrict__ WT, const DropMask& dm, int pair) {
+    for (int i = threadIdx.x; i < TR * SX; i += NT) {
+        const int r = i / SX, k = i % SX;
         l.xs[i] = (row_base + r < rows && k < F) ? xb[(row_base + r) * F + k] : 0.0f;
     }
     __syncthreads();
-    const float* wt0 = WT + flat_w_off(F, 0);
-    dense_forward_in<H1>(l.xs, F, wt0, WT + flat_b_off(F, 0), l.h1, ms, pair, rows, row_base);
+    // layer 0: k runs over the F real columns only (the next flat entry after W0^T is the bias, never read as a weight)
+    dense_forward<MODE, H1, SX, S1>(l.xs, F, WT + flat_w_off(F, 0), WT + flat_b_off(F, 0), l.h1, dm, pair, rows, row_base, 0);
     __syncthreads();
-    dense_forward<H1, H2, H1>(l.h1, WT + flat_w_off(F, 1), WT + flat_b_off(F, 1), l.h2, ms, pair, rows, row_base, 1);
+    dense_forward<MODE, H2, S1, S2>(l.h1, H1, WT + flat_w_off(F, 1), WT + flat_b_off(F, 1), l.h2, dm, pair, rows, row_base, 1);
     __syncthreads();
-    dense_forward<H2, H3, H2>(l.h2, WT + flat_w_off(F, 2), WT + flat_b_off(F, 2), l.h3, ms, pair, rows, row_base, 2);
+    dense_forward<MODE, H3, S2, S3>(l.h2, H2, WT + flat_w_off(F, 2), WT + flat_b_off(F, 2), l.h3, dm, pair, rows, row_base, 2);
     __syncthreads();
     {  // layer 3: 64 -> 1; 8 threads per row
         const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
         const float* w3 = WT + flat_w_off(F, 3);
         float a = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a = fmaf(l.h3[r * H3 + part * 8 + k], w3[part * 8 + k], a);
+        for (int k = 0; k < 8; ++k) a = fmaf(l.h3[r * S3 + part * 8 + k], w3[part * 8 + k], a);
         a += __shfl_xor(a, 1);
         a += __shfl_xor(a, 2);
         a += __shfl_xor(a, 4);
@@ -200,14 +234,15 @@ __global__ __launch_bounds__(256) void train_sample_kernel(const float* __restri
 }
 
 // T2: train-mode forward, one workgroup per pair ---------------------------------------------------
+template <int MODE>
 __global__ __launch_bounds__(NT, 1) void train_forward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
-                                                              const float* __restrict__ WT, MaskSrc ms, float* __restrict__ Y) {
+                                                              const float* __restrict__ WT, DropMask dm, float* __restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S;
     const int64_t P = flat_param_count(F);
     for (int64_t row_base = 0; row_base < rows; row_base += TR) {
-        forward_tile(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, ms, pair);
+        forward_tile<MODE>(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
         __syncthreads();
     }
@@ -280,8 +315,9 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
 }
 
 // T4: backward of one pair: recompute the forward tile, then back-propagate -----------------------
+template <int MODE>
 __global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
-                                                               const float* __restrict__ W, const float* __restrict__ WT, MaskSrc ms,
+                                                               const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
                                                                const float* __restrict__ delta, float* __restrict__ dW) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
@@ -289,22 +325,17 @@ __global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __re
     const int64_t P = flat_param_count(F);
     const float* w = W + (int64_t)pair * P;
     float* g = dW + (int64_t)pair * P;
-    const float sc = ms.mode != 0 ? ms.scale : 1.0f;
-    float* d2 = l.gc;            // dz2 [TR][64]
-    float* d2t = l.gc + TR * H3; // dz2^T [64][TR]
-    float* d1 = l.gb;            // dz1 [TR][128]
-    float* d1t = l.gb + TR * H2; // dz1^T [128][TR]
-    float* d0 = l.ga;            // dz0 [TR][256]
+    const float sc = MODE != 0 ? dm.scale : 1.0f;
     for (int64_t row_base = 0; row_base < rows; row_base += TR) {
         const bool first = row_base == 0;
-        forward_tile(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, ms, pair);
+        forward_tile<MODE>(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         // ---- layer 3: dw3[k] = sum_r dy[r] h3[r][k], db3 = sum_r dy[r]; dz2 = dy * w3 * d(h3)
         if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
         __syncthreads();
         if (t < H3) {
             float a = 0.0f;
 #pragma unroll
-            for (int r = 0; r < TR; ++r) a = fmaf(l.y[r], l.h3[r * H3 + t], a);
+            for (int r = 0; r < TR; ++r) a = fmaf(l.y[r], l.h3[r * S3 + t], a);
             float* p = g + flat_w_off(F, 3) + t;
             *p = first ? a : *p + a;
         } else if (t == H3) {
@@ -316,134 +347,22 @@ __global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __re
         }
         for (int i = t; i < TR * H3; i += NT) {
             const int r = i / H3, k = i % H3;
-            const float v = l.y[r] * w[flat_w_off(F, 3) + k] * dfactor(l.h3[i], sc);
-            d2[i] = v;
-            d2t[k * TR + r] = v;
+            l.d3[r * S3 + k] = l.y[r] * w[flat_w_off(F, 3) + k] * dfactor(l.h3[r * S3 + k], sc);
         }
         __syncthreads();
-        // ---- layer 2 weights: dW2[o][k] = sum_r dz2[r][o] h2[r][k]  (64 x 128), db2
-        {
-            const int k = t % H2, og = t / H2;  // 2 groups of 32 outputs
-            float hk[TR];
-#pragma unroll
-            for (int r = 0; r < TR; ++r) hk[r] = l.h2[r * H2 + k];
-            for (int o = og * 32; o < og * 32 + 32; ++o) {
-                float a = 0.0f;
-#pragma unroll
-                for (int r4 = 0; r4 < TR; r4 += 4) {
-                    const float4 z = *reinterpret_cast<const float4*>(d2t + o * TR + r4);
-                    a = fmaf(z.x, hk[r4], a);
-                    a = fmaf(z.y, hk[r4 + 1], a);
-                    a = fmaf(z.z, hk[r4 + 2], a);
-                    a = fmaf(z.w, hk[r4 + 3], a);
-                }
-                float* p = g + flat_w_off(F, 2) + (int64_t)o * H2 + k;
-                *p = first ? a : *p + a;
-            }
-            if (t < H3) {
-                float a = 0.0f;
-#pragma unroll
-                for (int r = 0; r < TR; ++r) a += d2t[t * TR + r];
-                float* p = g + flat_b_off(F, 2) + t;
-                *p = first ? a : *p + a;
-            }
-        }
-        // ---- dz1[r][k] = (sum_o dz2[r][o] W2[o][k]) * d(h2[r][k])   (k < 128)
-        {
-            const int k = t % H2, rg = t / H2;  // 2 row groups of 16
-            float a[16];
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) a[rr] = 0.0f;
-            const float* w2 = w + flat_w_off(F, 2);
-            for (int o = 0; o < H3; o += 4) {
-                const float w0 = w2[(o + 0) * H2 + k], w1 = w2[(o + 1) * H2 + k], w2v = w2[(o + 2) * H2 + k], w3 = w2[(o + 3) * H2 + k];
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const float4 z = *reinterpret_cast<const float4*>(d2 + (rg * 16 + rr) * H3 + o);
-                    a[rr] = fmaf(z.x, w0, a[rr]);
-                    a[rr] = fmaf(z.y, w1, a[rr]);
-                    a[rr] = fmaf(z.z, w2v, a[rr]);
-                    a[rr] = fmaf(z.w, w3, a[rr]);
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-                const int r = rg * 16 + rr;
-                const float v = a[rr] * dfactor(l.h2[r * H2 + k], sc);
-                d1[r * H2 + k] = v;
-                d1t[k * TR + r] = v;
-            }
-        }
+        // ---- layer 2: dW2 = dz2^T h2 (64 x 128), db2; dz1 = (dz2 W2) * d(h2)
+        weight_grad<H3, S3, S2>(l.d3, l.h2, H2, g + flat_w_off(F, 2), first);
+        bias_grad<H3, S3>(l.d3, g + flat_b_off(F, 2), first);
+        input_grad<H3, H2, S3, S2>(l.d3, w + flat_w_off(F, 2), l.h2, sc, l.d2);
         __syncthreads();
-        // ---- layer 1 weights: dW1[o][k] = sum_r dz1[r][o] h1[r][k]  (128 x 256), db1
-        {
-            const int k = t;  // 256 threads = 256 inputs
-            float hk[TR];
-#pragma unroll
-            for (int r = 0; r < TR; ++r) hk[r] = l.h1[r * H1 + k];
-            for (int o = 0; o < H2; ++o) {
-                float a = 0.0f;
-#pragma unroll
-                for (int r4 = 0; r4 < TR; r4 += 4) {
-                    const float4 z = *reinterpret_cast<const float4*>(d1t + o * TR + r4);
-                    a = fmaf(z.x, hk[r4], a);
-                    a = fmaf(z.y, hk[r4 + 1], a);
-                    a = fmaf(z.z, hk[r4 + 2], a);
-                    a = fmaf(z.w, hk[r4 + 3], a);
-                }
-                float* p = g + flat_w_off(F, 1) + (int64_t)o * H1 + k;
-                *p = first ? a : *p + a;
-            }
-            if (t < H2) {
-                float a = 0.0f;
-#pragma unroll
-                for (int r = 0; r < TR; ++r) a += d1t[t * TR + r];
-                float* p = g + flat_b_off(F, 1) + t;
-                *p = first ? a : *p + a;
-            }
-        }
-        // ---- dz0[r][k] = (sum_o dz1[r][o] W1[o][k]) * d(h1[r][k])   (k < 256)
-        {
-            const int k = t;
-            float a[TR];
-#pragma unroll
-            for (int r = 0; r < TR; ++r) a[r] = 0.0f;
-            const float* w1 = w + flat_w_off(F, 1);
-            for (int o = 0; o < H2; o += 4) {
-                const float w0 = w1[(o + 0) * H1 + k], w1v = w1[(o + 1) * H1 + k], w2v = w1[(o + 2) * H1 + k], w3 = w1[(o + 3) * H1 + k];
-#pragma unroll
-                for (int r = 0; r < TR; ++r) {
-                    const float4 z = *reinterpret_cast<const float4*>(d1 + r * H2 + o);
-                    a[r] = fmaf(z.x, w0, a[r]);
-                    a[r] = fmaf(z.y, w1v, a[r]);
-                    a[r] = fmaf(z.z, w2v, a[r]);
-                    a[r] = fmaf(z.w, w3, a[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < TR; ++r) d0[r * H1 + k] = a[r] * dfactor(l.h1[r * H1 + k], sc);
-        }
+        // ---- layer 1: dW1 = dz1^T h1 (128 x 256), db1; dz0 = (dz1 W1) * d(h1)
+        weight_grad<H2, S2, S1>(l.d2, l.h1, H1, g + flat_w_off(F, 1), first);
+        bias_grad<H2, S2>(l.d2, g + flat_b_off(F, 1), first);
+        input_grad<H2, H1, S2, S1>(l.d2, w + flat_w_off(F, 1), l.h1, sc, l.d1);
         __syncthreads();
-        // ---- layer 0 weights: dW0[o][k] = sum_r dz0[r][o] x[r][k]  (256 x F), db0
-        {
-            const int o = t;
-            float z[TR];
-            float bsum = 0.0f;
-#pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                z[r] = d0[r * H1 + o];
-                bsum += z[r];
-            }
-            for (int k = 0; k < F; ++k) {
-                float a = 0.0f;
-#pragma unroll
-                for (int r = 0; r < TR; ++r) a = fmaf(z[r], l.xs[r * XS + k], a);
-                float* p = g + (int64_t)o * F + k;
-                *p = first ? a : *p + a;
-            }
-            float* p = g + flat_b_off(F, 0) + o;
-            *p = first ? bsum : *p + bsum;
-        }
+        // ---- layer 0: dW0 = dz0^T x (256 x F), db0
+        weight_grad<H1, S1, SX>(l.d1, l.xs, F, g + flat_w_off(F, 0), first);
+        bias_grad<H1, S1>(l.d1, g + flat_b_off(F, 0), first);
         __syncthreads();
     }
 }
@@ -549,25 +468,28 @@ int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F
     return check_launch("train_sample");
 }
 
-static MaskSrc make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t seed, float p_drop) {
-    MaskSrc ms;
-    ms.m0 = m0;
-    ms.m1 = m1;
-    ms.m2 = m2;
-    ms.seed = seed;
-    ms.mode = mode;
-    ms.keep_prob = 1.0f - p_drop;
-    ms.scale = (float)(1.0 / (1.0 - (double)p_drop));  // torch: scale = 1/(1-p) in double, applied as fp32
-    return ms;
+static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t seed, float p_drop) {
+    DropMask dm{};
+    dm.m[0] = m0;
+    dm.m[1] = m1;
+    dm.m[2] = m2;
+    dm.seed = seed;
+    dm.mode = mode;
+    dm.keep_prob = 1.0f - p_drop;
+    dm.scale = (float)(1.0 / (1.0 - (double)p_drop));  // torch: scale = 1/(1-p) in double, applied as fp32
+    dm.M = 1;  // the pair index IS the global pair id (member * S + sample)
+    dm.S = 1;
+    dm.pair_begin = 0;
+    return dm;
 }
 
 int launch_train_forward(const float* xb, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = mask_mode == 1 ? train_forward_kernel<1> : mask_mode == 2 ? train_forward_kernel<2> : train_forward_kernel<0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(train_forward_kernel, dim3(M * S), dim3(NT), lds, s, xb, rows, F, S, WT,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
+    hipLaunchKernelGGL(kern, dim3(M * S), dim3(NT), lds, s, xb, rows, F, S, WT, make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
     return check_launch("train_forward");
 }
 
@@ -581,10 +503,11 @@ int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, co
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
                           float* dW, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(train_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto kern = mask_mode == 1 ? train_backward_kernel<1> : mask_mode == 2 ? train_backward_kernel<2> : train_backward_kernel<0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(train_backward_kernel, dim3(M * S), dim3(NT), lds, s, xb, rows, F, S, W, WT,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW);
+    hipLaunchKernelGGL(kern, dim3(M * S), dim3(NT), lds, s, xb, rows, F, S, W, WT, make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop),
+                       delta, dW);
     return check_launch("train_backward");
 }
 
