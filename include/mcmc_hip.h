@@ -192,6 +192,17 @@ int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_
                         int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
                         const uint8_t* mask2, uint64_t mask_seed, float p_drop,
                         const float* delta, float* dW, mcmc_stream_t stream);
+/* Large batches (BASELINE config 5: 10^5..10^6 rows per rank and step; the reference's batch is 32 rows,
+ * bayesian_ensemble.py:124, so it has no counterpart): each pair's rows are split into row_blocks runs of
+ * whole 32-row tiles, one workgroup each, and dW [M*S*row_blocks, P] receives one partial per block
+ * (mcmc_train_grad sums them).  mcmc_train_row_blocks(rows) is the split the library recommends (1 up to
+ * 2,047 rows).  mcmc_train_forward splits its rows the same way internally. */
+int mcmc_train_row_blocks(int64_t rows);
+int mcmc_train_backward_blocks(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim,
+                               int n_members, int n_samples, const float* W, const float* WT,
+                               int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
+                               const uint8_t* mask2, uint64_t mask_seed, float p_drop,
+                               const float* delta, int row_blocks, float* dW, mcmc_stream_t stream);
 /* gmu = sum_s dW, grho = sum_s dW*eps*sigma; clip_grad_norm_(max_norm) per member (:179); AdamW
  * with torch's update rule (:180) on members whose active flag is set (NULL = all); refreshes
  * sigma.  step = 1-based step count for the bias corrections.  adam_m/adam_v: [M,2P] (mu then
@@ -206,12 +217,12 @@ int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_
 
 /* The two halves of mcmc_train_update for the data-parallel step (BASELINE config 5, SURVEY.md 8e:
  * rows of each member's batch sharded over ranks): mcmc_train_grad forms this rank's (gmu, grho)
- * from its dW; the caller sum-all-reduces them (RCCL; the reference has no counterpart - it is
+ * from its dW [M*S*row_blocks, P] (row_blocks = 1 with mcmc_train_backward); the caller sum-all-reduces them (RCCL; the reference has no counterpart - it is
  * single-process, loss.backward() at bayesian_ensemble.py:178 sees the whole batch);
  * mcmc_train_apply recomputes the norm of the combined gradient, then clips and applies AdamW
  * exactly as mcmc_train_update does (:179-180). */
-int mcmc_train_grad(mcmc_ctx* ctx, int n_members, int n_samples, int input_dim, const float* eps,
-                    const float* sigma, const float* dW, float* gmu, float* grho,
+int mcmc_train_grad(mcmc_ctx* ctx, int n_members, int n_samples, int row_blocks, int input_dim,
+                    const float* eps, const float* sigma, const float* dW, float* gmu, float* grho,
                     double* norm_scratch, mcmc_stream_t stream);
 int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members,
                      int input_dim, const float* gmu, const float* grho, float* adam_m,

@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 6; }
+int mcmc_abi_version(void) { return 7; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -321,15 +321,33 @@ int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_member
     return launch_train_loss(Y, yb, n_members, n_samples, rows, alpha, beta, delta, loss, (hipStream_t)stream);
 }
 
-int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
-                        const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
-                        uint64_t mask_seed, float p_drop, const float* delta, float* dW, mcmc_stream_t stream) {
+static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
+                               const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
+                               uint64_t mask_seed, float p_drop, const float* delta, int row_blocks, float* dW, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && W && WT && delta && dW, "NULL pointer");
+    MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     return launch_train_backward(xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
-                                 delta, dW, (hipStream_t)stream);
+                                 delta, row_blocks, dW, (hipStream_t)stream);
+}
+
+int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
+                        const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
+                        uint64_t mask_seed, float p_drop, const float* delta, float* dW, mcmc_stream_t stream) {
+    return train_backward_impl(ctx, xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
+                               delta, 1, dW, stream);
+}
+
+int mcmc_train_row_blocks(int64_t rows) { return train_row_blocks(rows < 0 ? 0 : rows); }
+
+int mcmc_train_backward_blocks(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples,
+                               const float* W, const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
+                               const uint8_t* mask2, uint64_t mask_seed, float p_drop, const float* delta, int row_blocks, float* dW,
+                               mcmc_stream_t stream) {
+    return train_backward_impl(ctx, xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
+                               delta, row_blocks, dW, stream);
 }
 
 int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }
@@ -347,12 +365,13 @@ int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_
                                lr, beta1, beta2, adam_eps, weight_decay, max_norm, step, gnorm, (hipStream_t)stream);
 }
 
-int mcmc_train_grad(mcmc_ctx* ctx, int n_members, int n_samples, int input_dim, const float* eps, const float* sigma, const float* dW,
-                    float* gmu, float* grho, double* norm_scratch, mcmc_stream_t stream) {
+int mcmc_train_grad(mcmc_ctx* ctx, int n_members, int n_samples, int row_blocks, int input_dim, const float* eps, const float* sigma,
+                    const float* dW, float* gmu, float* grho, double* norm_scratch, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, input_dim, 1)) return rc;
+    MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     MCMC_REQUIRE(eps && sigma && dW && gmu && grho && norm_scratch, "NULL pointer");
-    return launch_train_grad(n_members, n_samples, input_dim, eps, sigma, dW, gmu, grho, norm_scratch, (hipStream_t)stream);
+    return launch_train_grad(n_members, n_samples, row_blocks, input_dim, eps, sigma, dW, gmu, grho, norm_scratch, (hipStream_t)stream);
 }
 
 int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members, int input_dim, const float* gmu,

@@ -76,9 +76,10 @@ int launch_train_loss(const float* Y, const float* yb, int M, int S, int64_t row
                       hipStream_t s);
 int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                          float* dW, hipStream_t s);
-int launch_train_grad(int M, int S, int F, const float* eps, const float* sigma, const float* dW, float* gmu, float* grho,
-                      double* normsq_part, hipStream_t s);
+                          int row_blocks, float* dW, hipStream_t s);
+int launch_train_grad(int M, int S, int row_blocks, int F, const float* eps, const float* sigma, const float* dW, float* gmu,
+                      float* grho, double* normsq_part, hipStream_t s);
+int train_row_blocks(int64_t rows);
 int launch_train_apply(float* mu, float* rho, float* sigma, int M, int F, const float* gmu, const float* grho, float* am, float* av,
                        double* normsq_part, bool recompute_norm, const uint8_t* active, float lr, float beta1, float beta2,
                        float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s);

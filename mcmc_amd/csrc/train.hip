@@ -34,6 +34,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // A[r][h] and B[h][r]; afterwards register i of lane (r, h) holds D[acc_feature(i, h)][r] (layout.hpp).
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
 
+// expm1 for the ELU's negative branch by Kahan's correction, expm1(z) = (u - 1) * z / log(u) with u = exp(z):
+// ~10 instructions (v_exp_f32, v_log_f32, one division) against ocml expm1f's ~45, within 2 ulp of it.
+__device__ __forceinline__ float elu_neg(float z) {
+    const float u = __expf(z), um1 = u - 1.0f;
+    float r = um1 * __fdividef(z, __logf(u));  // branch-free: the two special cases are selects
+    r = u == 1.0f ? z : r;                     // |z| below half an ulp of 1
+    return um1 == -1.0f ? -1.0f : r;           // exp underflowed
+}
+
 // ---- dense layers on LDS tiles, MFMA ---------------------------------------------------------------
 // Z^T[out, row] = b[out] + sum_k WT[k][out] * hin[row][k]; then h = elu(z) * mask * scale -> hout[row][out].
 // A comes straight from the pre-sampled WT image in global memory / L2 (32 consecutive floats per lane half),
@@ -45,6 +54,7 @@ __device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int
                                               int64_t rows, int64_t row_base, int layer) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const bool live = row_base + r < rows;
+#pragma unroll 1
     for (int mo = wave; mo < OUT / 32; mo += NW) {
         f32x16 acc;
 #pragma unroll
@@ -65,6 +75,7 @@ __device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int
             for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st)
                 if (2 * st < K) acc = mfma2(av[st], bv[st], acc);
         } else {
+#pragma unroll 1
             for (int s0 = 0; s0 < K / 2; s0 += 32) {
                 float av[32];
 #pragma unroll
@@ -75,7 +86,7 @@ __device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int
         }
         float o[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = acc[i] > 0.0f ? acc[i] : expm1f(acc[i]);
+        for (int i = 0; i < 16; ++i) o[i] = acc[i] > 0.0f ? acc[i] : elu_neg(acc[i]);
         drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row_base + r);
 #pragma unroll
         for (int i = 0; i < 16; ++i) hout[r * OUT_STRIDE + 32 * mo + acc_feature(i, h)] = live ? o[i] : -0.0f;
@@ -94,6 +105,7 @@ __device__ __forceinline__ void weight_grad(const float* __restrict__ dz, const 
                                             bool first) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
     const int n_in = (IN + 31) / 32;
+#pragma unroll 1
     for (int tile = wave; tile < (OUT / 32) * n_in; tile += NW) {
         const int mo = tile / n_in, ni = tile % n_in;
         f32x16 acc = {0};
@@ -129,10 +141,12 @@ template <int OUT, int IN, int DZ_STRIDE, int IN_STRIDE>
 __device__ __forceinline__ void input_grad(const float* __restrict__ dz, const float* __restrict__ W, const float* __restrict__ hin,
                                            float scale, float* __restrict__ dzin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+#pragma unroll 1
     for (int mi = wave; mi < IN / 32; mi += NW) {
         f32x16 acc = {0};
         const float* a = W + 32 * mi + r;
         const float* b = dz + r * DZ_STRIDE;
+#pragma unroll 1
         for (int s0 = 0; s0 < OUT / 2; s0 += 32) {
             float av[32];
 #pragma unroll
@@ -159,6 +173,7 @@ struct Lds {
     float* y;    // [TR] outputs, then dLoss/dy in the backward pass
 };
 constexpr int kLdsFloats = TR * (SX + 2 * (S1 + S2 + S3) + 1);
+constexpr int kLdsFloatsFwd = TR * (SX + S1 + S2 + S3 + 1);  // forward only: two workgroups per CU
 
 __device__ __forceinline__ Lds carve(float* base) {
     Lds l;
@@ -166,10 +181,10 @@ __device__ __forceinline__ Lds carve(float* base) {
     l.h1 = l.xs + TR * SX;
     l.h2 = l.h1 + TR * S1;
     l.h3 = l.h2 + TR * S2;
-    l.d1 = l.h3 + TR * S3;
+    l.y = l.h3 + TR * S3;
+    l.d1 = l.y + TR;  // the gradient tiles exist in the backward kernel's allocation only
     l.d2 = l.d1 + TR * S1;
     l.d3 = l.d2 + TR * S2;
-    l.y = l.d3 + TR * S3;
     return l;
 }
 
@@ -235,13 +250,16 @@ __global__ __launch_bounds__(256) void train_sample_kernel(const float* __restri
 
 // T2: train-mode forward, one workgroup per pair ---------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(NT, 1) void train_forward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
+__global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
                                                               const float* __restrict__ WT, DropMask dm, float* __restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S;
     const int64_t P = flat_param_count(F);
-    for (int64_t row_base = 0; row_base < rows; row_base += TR) {
+    // rows of a large batch are split over blockIdx.y in runs of whole tiles
+    const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
+    const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
+    for (int64_t row_base = begin; row_base < end; row_base += TR) {
         forward_tile<MODE>(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
         __syncthreads();
@@ -324,10 +342,17 @@ __global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __re
     const int pair = blockIdx.x, m = pair / S, t = threadIdx.x;
     const int64_t P = flat_param_count(F);
     const float* w = W + (int64_t)pair * P;
-    float* g = dW + (int64_t)pair * P;
+    // row block blockIdx.y accumulates its own partial dW[pair * row_blocks + block] (summed by train_grad_kernel)
+    float* g = dW + ((int64_t)pair * gridDim.y + blockIdx.y) * P;
     const float sc = MODE != 0 ? dm.scale : 1.0f;
-    for (int64_t row_base = 0; row_base < rows; row_base += TR) {
-        const bool first = row_base == 0;
+    const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
+    const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
+    if (begin >= end) {  // more blocks than tiles: this partial is zero
+        for (int64_t i = t; i < P; i += NT) g[i] = 0.0f;
+        return;
+    }
+    for (int64_t row_base = begin; row_base < end; row_base += TR) {
+        const bool first = row_base == begin;
         forward_tile<MODE>(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         // ---- layer 3: dw3[k] = sum_r dy[r] h3[r][k], db3 = sum_r dy[r]; dz2 = dy * w3 * d(h3)
         if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
@@ -369,15 +394,17 @@ __global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __re
 
 // T5: gradients of (mu, rho) from the per-pair weight gradients + per-block squared norms ----------
 __global__ __launch_bounds__(256) void train_grad_kernel(const float* __restrict__ dW, const float* __restrict__ eps,
-                                                        const float* __restrict__ sigma, int S, int64_t P, float* __restrict__ gmu,
-                                                        float* __restrict__ grho, double* __restrict__ normsq_part) {
+                                                        const float* __restrict__ sigma, int S, int NB, int64_t P,
+                                                        float* __restrict__ gmu, float* __restrict__ grho,
+                                                        double* __restrict__ normsq_part) {
     __shared__ double red[4];
     const int m = blockIdx.y;
     double nsq = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         float a = 0.0f, b = 0.0f;
         for (int s = 0; s < S; ++s) {  // fixed order: deterministic
-            const float d = dW[((int64_t)m * S + s) * P + i];
+            float d = dW[((int64_t)m * S + s) * NB * P + i];
+            for (int nb = 1; nb < NB; ++nb) d += dW[(((int64_t)m * S + s) * NB + nb) * P + i];  // row-block partials
             a += d;
             b = fmaf(d, eps[((int64_t)m * S + s) * P + i], b);
         }
@@ -485,11 +512,12 @@ static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const 
 
 int launch_train_forward(const float* xb, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s) {
-    const size_t lds = kLdsFloats * sizeof(float);
+    const size_t lds = kLdsFloatsFwd * sizeof(float);
     auto kern = mask_mode == 1 ? train_forward_kernel<1> : mask_mode == 2 ? train_forward_kernel<2> : train_forward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(M * S), dim3(NT), lds, s, xb, rows, F, S, WT, make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
+    hipLaunchKernelGGL(kern, dim3(M * S, train_row_blocks(rows)), dim3(NT), lds, s, xb, rows, F, S, WT,
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
     return check_launch("train_forward");
 }
 
@@ -501,20 +529,21 @@ int launch_train_loss(const float* Y, const float* yb, int M, int S, int64_t row
 
 int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                          float* dW, hipStream_t s) {
+                          int row_blocks, float* dW, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_backward_kernel<1> : mask_mode == 2 ? train_backward_kernel<2> : train_backward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(M * S), dim3(NT), lds, s, xb, rows, F, S, W, WT, make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop),
-                       delta, dW);
+    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), lds, s, xb, rows, F, S, W, WT,
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW);
     return check_launch("train_backward");
 }
 
-int launch_train_grad(int M, int S, int F, const float* eps, const float* sigma, const float* dW, float* gmu, float* grho,
-                      double* normsq_part, hipStream_t s) {
+int launch_train_grad(int M, int S, int row_blocks, int F, const float* eps, const float* sigma, const float* dW, float* gmu,
+                      float* grho, double* normsq_part, hipStream_t s) {
     const int64_t P = flat_param_count(F);
-    hipLaunchKernelGGL(train_grad_kernel, dim3(kGradBlocks, M), dim3(256), 0, s, dW, eps, sigma, S, P, gmu, grho, normsq_part);
+    hipLaunchKernelGGL(train_grad_kernel, dim3(kGradBlocks, M), dim3(256), 0, s, dW, eps, sigma, S, row_blocks, P, gmu, grho,
+                       normsq_part);
     return check_launch("train_grad");
 }
 
@@ -540,11 +569,18 @@ int launch_train_apply(float* mu, float* rho, float* sigma, int M, int F, const 
 int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F, const float* eps, const float* dW, float* gmu,
                         float* grho, float* am, float* av, double* normsq_part, const uint8_t* active, float lr, float beta1,
                         float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s) {
-    if (int rc = launch_train_grad(M, S, F, eps, sigma, dW, gmu, grho, normsq_part, s)) return rc;
+    if (int rc = launch_train_grad(M, S, 1, F, eps, sigma, dW, gmu, grho, normsq_part, s)) return rc;
     return launch_train_apply(mu, rho, sigma, M, F, gmu, grho, am, av, normsq_part, false, active, lr, beta1, beta2, adam_eps,
                               weight_decay, max_norm, step, gnorm, s);
 }
 
 int train_grad_blocks() { return kGradBlocks; }
+
+// Row blocks a batch of `rows` rows per member is split into (each pair then runs on that many workgroups):
+// one up to 2,047 rows - the reference's 32-row batches - then one per 1,024 rows, at most 64.
+int train_row_blocks(int64_t rows) {
+    const int64_t nb = rows / 1024;
+    return (int)(nb < 1 ? 1 : nb > 64 ? 64 : nb);
+}
 
 }  // namespace mcmc

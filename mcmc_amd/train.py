@@ -62,7 +62,7 @@ class EnsembleTrainer:
         self.eps = torch.empty(pairs, self.P, **f32)
         self.W = torch.empty(pairs, self.P, **f32)
         self.WT = torch.empty(pairs, self.P, **f32)
-        self.dW = torch.empty(pairs, self.P, **f32)
+        self.dW = torch.empty(pairs, self.P, **f32)  # [pairs * row_blocks, P] once a large batch arrives
         self.grad = torch.empty(2, self.M, self.P, **f32)  # one buffer: the data-parallel step all-reduces it in one call
         self.gmu, self.grho = self.grad[0], self.grad[1]
         self.adam_m = torch.zeros(self.M, 2 * self.P, **f32)
@@ -140,13 +140,17 @@ class EnsembleTrainer:
         else:
             _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, self.alpha, self.beta, _p(delta), _p(self.loss), st),
                        "mcmc_train_loss")
-        _lib.check(lib.mcmc_train_backward(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
-                                           self.p_drop, _p(delta), _p(self.dW), st), "mcmc_train_backward")
-        if update and dp:
+        nb = int(lib.mcmc_train_row_blocks(rows))  # > 1 for large batches: each pair's rows run on nb workgroups
+        if self.dW.shape[0] < M * S * nb:
+            self.dW = torch.empty(M * S * nb, self.P, dtype=torch.float32, device=self.eng.device)
+        _lib.check(lib.mcmc_train_backward_blocks(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2),
+                                                  mseed, self.p_drop, _p(delta), nb, _p(self.dW), st), "mcmc_train_backward_blocks")
+        if update and (dp or nb > 1):
             self.t += 1
-            _lib.check(lib.mcmc_train_grad(h, M, S, F, _p(self.eps), _p(self.sigma), _p(self.dW), _p(self.gmu), _p(self.grho),
+            _lib.check(lib.mcmc_train_grad(h, M, S, nb, F, _p(self.eps), _p(self.sigma), _p(self.dW), _p(self.gmu), _p(self.grho),
                                            _p(self.norm_scratch), st), "mcmc_train_grad")
-            all_reduce_sum(self.grad, group)
+            if dp:
+                all_reduce_sum(self.grad, group)
             _lib.check(lib.mcmc_train_apply(h, _p(self.mu), _p(self.rho), _p(self.sigma), M, F, _p(self.gmu), _p(self.grho),
                                             _p(self.adam_m), _p(self.adam_v), _p(self.norm_scratch), _p(active), lr, beta1, self.beta2,
                                             self.adam_eps, self.weight_decay, self.max_norm, self.t, _p(self.gnorm), st),
