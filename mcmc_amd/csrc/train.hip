@@ -219,32 +219,87 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const float* __restri
 }
 
 // T1: eps, effective weights in both layouts ------------------------------------------------------
+// One workgroup = one 32 x 32 tile of one layer's weight matrix of one pair (or the biases + output layer):
+// noise, W = mu + eps * sigma and eps are written along the input index (the flat layout), the tile goes
+// through LDS, and WT is written along the output index - both global writes are lane-contiguous.
+// Layers 1-2: a thread owns four consecutive inputs of one output row = one Philox block (philox_normal4).
+__device__ __forceinline__ float sample_one(const float* __restrict__ mu, const float* __restrict__ sigma, int noise_mode,
+                                            const float* __restrict__ eps_in, uint64_t seed, int pair, int64_t P, int m, int64_t i,
+                                            float& e) {
+    e = 0.0f;
+    if (noise_mode == MCMC_NOISE_INJECTED) e = eps_in[(int64_t)pair * P + i];
+    else if (noise_mode == MCMC_NOISE_PHILOX) e = philox_normal(seed, (uint32_t)pair, (uint32_t)i);
+    return noise_mode == MCMC_NOISE_NONE ? mu[m * P + i] : __fadd_rn(mu[m * P + i], __fmul_rn(e, sigma[m * P + i]));
+}
+
+constexpr int kSampleTiles = 8 + 32 + 8 + 1;  // layer 0 (8 x 1), layer 1 (4 x 8), layer 2 (2 x 4), the rest
+
 __global__ __launch_bounds__(256) void train_sample_kernel(const float* __restrict__ mu, const float* __restrict__ sigma, int S, int F,
                                                           int noise_mode, const float* __restrict__ eps_in, uint64_t seed,
                                                           float* __restrict__ eps, float* __restrict__ W, float* __restrict__ WT) {
+    __shared__ float tl[32][33];
     const int64_t P = flat_param_count(F);
-    const int pair = blockIdx.y, m = pair / S;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        float e = 0.0f;
-        if (noise_mode == MCMC_NOISE_INJECTED) e = eps_in[(int64_t)pair * P + i];
-        else if (noise_mode == MCMC_NOISE_PHILOX) e = philox_normal(seed, (uint32_t)pair, (uint32_t)i);
-        const float w = noise_mode == MCMC_NOISE_NONE ? mu[m * P + i] : __fadd_rn(mu[m * P + i], __fmul_rn(e, sigma[m * P + i]));
-        eps[(int64_t)pair * P + i] = e;
-        W[(int64_t)pair * P + i] = w;
-        // transposed position inside the same layer block
-        int layer = 3;
-        if (i < flat_w_off(F, 1)) layer = 0;
-        else if (i < flat_w_off(F, 2)) layer = 1;
-        else if (i < flat_w_off(F, 3)) layer = 2;
-        const int64_t wo = flat_w_off(F, layer), bo = flat_b_off(F, layer);
-        int64_t j = i;
-        if (i < bo) {
-            const int in = layer_in(F, layer), out = layer_out(layer);
-            const int64_t l = i - wo;
-            const int o = (int)(l / in), k = (int)(l % in);
-            j = wo + (int64_t)k * out + o;
+    const int pair = blockIdx.y, m = pair / S, t = threadIdx.x;
+    const int64_t base = (int64_t)pair * P;
+    int tile = blockIdx.x;
+    if (tile >= 48) {  // biases of the hidden layers, then the output layer (w3 [1 x 64] is its own transpose)
+        const int64_t lo[4] = {flat_b_off(F, 0), flat_b_off(F, 1), flat_b_off(F, 2), flat_w_off(F, 3)};
+        const int n[4] = {H1, H2, H3, H3 + 1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            for (int k = t; k < n[q]; k += 256) {
+                float e;
+                const float w = sample_one(mu, sigma, noise_mode, eps_in, seed, pair, P, m, lo[q] + k, e);
+                eps[base + lo[q] + k] = e;
+                W[base + lo[q] + k] = w;
+                WT[base + lo[q] + k] = w;
+            }
+        return;
+    }
+    int layer = 0, n_in_tiles = 1;
+    if (tile >= 40) {
+        layer = 2;
+        tile -= 40;
+        n_in_tiles = H2 / 32;
+    } else if (tile >= 8) {
+        layer = 1;
+        tile -= 8;
+        n_in_tiles = H1 / 32;
+    }
+    const int to = tile / n_in_tiles, ti = tile % n_in_tiles;
+    const int in = layer_in(F, layer), out = layer_out(layer);
+    const int64_t wo = flat_w_off(F, layer);
+    const int ol = t >> 3, kl0 = (t & 7) * 4;  // output row and first of four inputs inside the tile
+    const int o = 32 * to + ol, k0 = 32 * ti + kl0;
+    const int64_t i0 = wo + (int64_t)o * in + k0;
+    if (layer > 0 && noise_mode == MCMC_NOISE_PHILOX) {
+        float e[4];
+        philox_normal4(seed, (uint32_t)pair, (uint32_t)(i0 >> 2), e);  // i0 % 4 == 0 for layers 1-2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w = __fadd_rn(mu[m * P + i0 + j], __fmul_rn(e[j], sigma[m * P + i0 + j]));
+            eps[base + i0 + j] = e[j];
+            W[base + i0 + j] = w;
+            tl[ol][kl0 + j] = w;
         }
-        WT[(int64_t)pair * P + j] = w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < in) {
+                float e;
+                const float w = sample_one(mu, sigma, noise_mode, eps_in, seed, pair, P, m, i0 + j, e);
+                eps[base + i0 + j] = e;
+                W[base + i0 + j] = w;
+                tl[ol][kl0 + j] = w;
+            }
+    }
+    __syncthreads();
+    // WT[k][o]: 32 consecutive outputs per input row
+    const int ol2 = t & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int kl = (t >> 5) + 8 * q, k = 32 * ti + kl;
+        if (k < in) WT[base + wo + (int64_t)k * out + 32 * to + ol2] = tl[ol2][kl];
     }
 }
 
@@ -480,7 +535,7 @@ __global__ __launch_bounds__(256) void exp_kernel(const float* __restrict__ rho,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) sigma[i] = expf(rho[i]);
 }
 
-constexpr int kGradBlocks = 32;
+constexpr int kGradBlocks = 128;
 
 }  // namespace
 
@@ -491,7 +546,8 @@ int launch_train_sigma(const float* rho, float* sigma, int64_t n, hipStream_t s)
 
 int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F, int noise_mode, const float* eps_in, uint64_t seed,
                         float* eps, float* W, float* WT, hipStream_t s) {
-    hipLaunchKernelGGL(train_sample_kernel, dim3(44, M * S), dim3(256), 0, s, mu, sigma, S, F, noise_mode, eps_in, seed, eps, W, WT);
+    hipLaunchKernelGGL(train_sample_kernel, dim3(kSampleTiles, M * S), dim3(256), 0, s, mu, sigma, S, F, noise_mode, eps_in, seed, eps, W,
+                       WT);
     return check_launch("train_sample");
 }
 
