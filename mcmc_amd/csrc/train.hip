@@ -506,8 +506,15 @@ __global__ __launch_bounds__(256) void train_adamw_kernel(float* __restrict__ mu
                                                          const uint8_t* __restrict__ active, AdamHyper hp, float* __restrict__ gnorm) {
     const int m = blockIdx.y;
     if (active && !active[m]) return;
-    double nsq = 0.0;
-    for (int i = 0; i < nparts; ++i) nsq += normsq_part[(int64_t)m * nparts + i];  // same order in every thread
+    // squared norm from the per-block partials (nparts <= 256): one partial per thread, a fixed shuffle tree per
+    // wave, then the four wave sums in order - the same value in every workgroup and every run
+    __shared__ double wsum[4];
+    double v = (int)threadIdx.x < nparts ? normsq_part[(int64_t)m * nparts + threadIdx.x] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double nsq = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     const float total = (float)sqrt(nsq);
     if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm) gnorm[m] = total;
     float coef = hp.max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
