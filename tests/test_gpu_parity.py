@@ -277,6 +277,12 @@ def test_ensemble_class_contract(golden):
     # main.py:174-177 consumer idiom
     _ = mean.cpu().rename(None).reshape(-1, 1)
     _ = std.cpu().rename(None) * 2.0
+    # opt-in MC dropout (extension): same seed, masks on -> a different, wider predictive distribution
+    plain = ens.predict_full(X, 100, seed=11, quantiles=())
+    mcd = ens.predict_full(X, 100, seed=11, quantiles=(), mc_dropout=True)
+    again = ens.predict_full(X, 100, seed=11, quantiles=(), mc_dropout=True)
+    assert torch.equal(mcd.mean, again.mean) and not torch.equal(mcd.mean, plain.mean)
+    assert float(mcd.std.mean()) > float(plain.std.mean())
 
 
 def test_config3_full_size_properties():
