@@ -9,6 +9,8 @@
 // The reference runs ~12 elementwise/reduce kernels forward plus autograd backward; here three
 // streaming passes, each reading p,t once with 16-B loads.  The global sums sit in device
 // memory (fp64) between passes so that data-parallel ranks can all-reduce them.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mcmc {
@@ -76,7 +78,27 @@ __global__ __launch_bounds__(kBlock) void loss_stats_kernel(const float* __restr
     const float4* p4 = reinterpret_cast<const float4*>(p);
     const float4* t4 = reinterpret_cast<const float4*>(t);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte load pairs in flight per thread
+        float4 a[4], b[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            a[v] = p4[i + v * stride];
+            b[v] = t4[i + v * stride];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float pv[4] = {a[v].x, a[v].y, a[v].z, a[v].w}, tv[4] = {b[v].x, b[v].y, b[v].z, b[v].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double td = (double)tv[u];
+                acc[0] += td;
+                acc[1] = fma(td, td, acc[1]);
+                acc[2] += (double)fabsf(pv[u] - tv[u]);
+            }
+        }
+    }
+    for (; i < n4; i += stride) {
         const float4 a = p4[i], b = t4[i];
         const float pv[4] = {a.x, a.y, a.z, a.w}, tv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -159,7 +181,9 @@ __global__ __launch_bounds__(kBlock) void loss_backward_kernel(const float* __re
 
 inline int loss_grid(const mcmc_ctx* ctx, int64_t n) {
     int64_t b = (n / 4 + kBlock - 1) / kBlock;
-    const int64_t cap = (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256) * 8;
+    // few, fat workgroups: every one ends with fp64 atomics on the same 2-3 addresses, which serialise
+    static const int per_cu = getenv("MCMC_LOSS_WG_PER_CU") ? atoi(getenv("MCMC_LOSS_WG_PER_CU")) : 4;  // dev knob
+    const int64_t cap = (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256) * (per_cu > 0 ? per_cu : 4);
     if (b > cap) b = cap;
     return (int)(b < 1 ? 1 : b);
 }
