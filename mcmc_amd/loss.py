@@ -8,7 +8,6 @@ like the reference's: three tiny all-reduces (4 + 2 scalars) around the passes.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 

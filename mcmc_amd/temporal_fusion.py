@@ -9,8 +9,7 @@ There is no CPU path.
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import List, Optional, Sequence, Tuple, Union
+from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch

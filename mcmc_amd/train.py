@@ -13,7 +13,6 @@ There is no CPU path.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -95,8 +94,8 @@ class EnsembleTrainer:
         count is shared).  Returns the per-member loss [M] (device tensor, no sync).
 
         Data-parallel (BASELINE config 5): with torch.distributed initialised and
-        ``group`` None (the default process group) or a group, xb / yb are THIS rank's rows of every member's batch.  Noise is keyed by
-        (seed, pair) so every rank draws the same weights; the loss statistics (mean / std of y,
+        ``group`` None (the default process group) or a group, xb / yb are THIS rank's rows of every
+        member's batch.  Noise is keyed by (seed, pair) so every rank draws the same weights; the loss statistics (mean / std of y,
         mean |e|, G) are global-batch through two all-reduces of [M,4] fp64 partials, each rank
         back-propagates its rows, and (gmu, grho) are sum-all-reduced (2*M*P fp32 = 354 KB per member)
         before the clip and the AdamW update, which every rank then applies identically.
@@ -166,7 +165,6 @@ class EnsembleTrainer:
     def _dp_loss(self, Y: torch.Tensor, yb: torch.Tensor, rows: int, delta: torch.Tensor, group, global_rows: Optional[int]):
         """peak_weighted_loss with global-batch statistics on the piece-3 kernels (mcmc_loss_*): per member
         p = mean over samples of this rank's rows; partial sums all-reduced between the passes."""
-        import torch.distributed as dist
         lib, h, st = self.eng.lib, self.eng.ctx.handle, _stream()
         M, S, dev = self.M, self.S, self.eng.device
         rp = (rows + 3) // 4 * 4  # 16-byte aligned member rows

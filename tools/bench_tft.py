@@ -5,7 +5,6 @@ formulation (full [B,T,T] attention, torch ops + autograd + torch.optim.AdamW) o
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
