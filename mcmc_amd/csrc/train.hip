@@ -111,15 +111,17 @@ __device__ __forceinline__ void weight_grad(const float* __restrict__ dz, const 
         f32x16 acc = {0};
         const float* a = dz + 32 * mo + r;
         const float* b = hin + 32 * ni + r;
+        const int in = 32 * ni + r;
+        // later tiles of a row block accumulate: the running sums are fetched before the MFMA chain and added
+        // after it, so their L2 round trip hides behind the chain
+        float prev[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[i] = (!first && in < IN) ? g[(int64_t)(32 * mo + acc_feature(i, h)) * IN + in] : 0.0f;
 #pragma unroll
         for (int k = 0; k < TR; k += 2) acc = mfma2(a[(k + h) * DZ_STRIDE], b[(k + h) * IN_STRIDE], acc);
-        const int in = 32 * ni + r;
         if (in < IN) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float* p = g + (int64_t)(32 * mo + acc_feature(i, h)) * IN + in;
-                *p = first ? acc[i] : *p + acc[i];
-            }
+            for (int i = 0; i < 16; ++i) g[(int64_t)(32 * mo + acc_feature(i, h)) * IN + in] = prev[i] + acc[i];
         }
     }
 }
