@@ -9,8 +9,8 @@
 //   clip_grad_norm_(1.0) (:179), AdamW step (:180; lr / beta1 come from the host's OneCycleLR).
 //
 // The batch is 32 rows (:124), so every GEMM here is one or a few 32x32 MFMA tiles.  One workgroup (4 waves)
-// owns one (member, sample) pair and keeps the activations and their gradients of a 32-row tile in LDS
-// ([row][feature] tiles with odd strides, 120 KB); the weights stream from L2 in two pre-sampled layouts
+// owns one (member, sample) pair and keeps the activations of a 32-row tile in LDS ([row][feature] tiles with
+// odd strides, 62 KB: two workgroups per CU; the backward pass turns them into gradients in place); the weights stream from L2 in two pre-sampled layouts
 // (WT [in][out] for the forward, W [out][in] for the input gradients) as MFMA A operands, 32 consecutive
 // floats per lane half.  All GEMMs run on v_mfma_f32_32x32x2_f32: exact fp32 FMAs, so the step stays
 // within 2e-5 of the reference's fp32 autograd.
@@ -139,9 +139,10 @@ __device__ __forceinline__ void bias_grad(const float* __restrict__ dz, float* _
 
 // dzin[r][in] = (sum_o dz[r][o] * W[o][in]) * d(hin[r][in]): A = rows of W [out][in] from global memory / L2,
 // B = columns of the dz tile.
+// dzin may be hin itself: every element is read (for d(.)) and then written by the same lane.
 template <int OUT, int IN, int DZ_STRIDE, int IN_STRIDE>
-__device__ __forceinline__ void input_grad(const float* __restrict__ dz, const float* __restrict__ W, const float* __restrict__ hin,
-                                           float scale, float* __restrict__ dzin) {
+__device__ __forceinline__ void input_grad(const float* __restrict__ dz, const float* __restrict__ W, const float* hin, float scale,
+                                           float* dzin) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
 #pragma unroll 1
     for (int mi = wave; mi < IN / 32; mi += NW) {
@@ -166,16 +167,12 @@ __device__ __forceinline__ void input_grad(const float* __restrict__ dz, const f
 
 struct Lds {
     float* xs;   // [TR][SX]  input tile, columns >= F are zero
-    float* h1;   // [TR][S1]
-    float* h2;   // [TR][S2]
+    float* h1;   // [TR][S1]  activations; the backward pass overwrites each tile in place with the gradient
+    float* h2;   // [TR][S2]  w.r.t. its pre-activations once the weight gradient that needs the activations is done
     float* h3;   // [TR][S3]
-    float* d1;   // dz0 [TR][S1]
-    float* d2;   // dz1 [TR][S2]
-    float* d3;   // dz2 [TR][S3]
     float* y;    // [TR] outputs, then dLoss/dy in the backward pass
 };
-constexpr int kLdsFloats = TR * (SX + 2 * (S1 + S2 + S3) + 1);
-constexpr int kLdsFloatsFwd = TR * (SX + S1 + S2 + S3 + 1);  // forward only: two workgroups per CU
+constexpr int kLdsFloats = TR * (SX + S1 + S2 + S3 + 1);  // 62 KB: two workgroups per CU, forward and backward
 
 __device__ __forceinline__ Lds carve(float* base) {
     Lds l;
@@ -184,9 +181,6 @@ __device__ __forceinline__ Lds carve(float* base) {
     l.h2 = l.h1 + TR * S1;
     l.h3 = l.h2 + TR * S2;
     l.y = l.h3 + TR * S3;
-    l.d1 = l.y + TR;  // the gradient tiles exist in the backward kernel's allocation only
-    l.d2 = l.d1 + TR * S1;
-    l.d3 = l.d2 + TR * S2;
     return l;
 }
 
@@ -391,7 +385,7 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
 
 // T4: backward of one pair: recompute the forward tile, then back-propagate -----------------------
 template <int MODE>
-__global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
+__global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
                                                                const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
                                                                const float* __restrict__ delta, float* __restrict__ dW) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -427,24 +421,27 @@ __global__ __launch_bounds__(NT, 1) void train_backward_kernel(const float* __re
             float* p = g + flat_b_off(F, 3);
             *p = first ? a : *p + a;
         }
+        __syncthreads();  // dw3 has read h3: dz2 may now replace it
         for (int i = t; i < TR * H3; i += NT) {
             const int r = i / H3, k = i % H3;
-            l.d3[r * S3 + k] = l.y[r] * w[flat_w_off(F, 3) + k] * dfactor(l.h3[r * S3 + k], sc);
+            l.h3[r * S3 + k] = l.y[r] * w[flat_w_off(F, 3) + k] * dfactor(l.h3[r * S3 + k], sc);
         }
         __syncthreads();
-        // ---- layer 2: dW2 = dz2^T h2 (64 x 128), db2; dz1 = (dz2 W2) * d(h2)
-        weight_grad<H3, S3, S2>(l.d3, l.h2, H2, g + flat_w_off(F, 2), first);
-        bias_grad<H3, S3>(l.d3, g + flat_b_off(F, 2), first);
-        input_grad<H3, H2, S3, S2>(l.d3, w + flat_w_off(F, 2), l.h2, sc, l.d2);
+        // ---- layer 2: dW2 = dz2^T h2 (64 x 128), db2; then dz1 = (dz2 W2) * d(h2) replaces h2
+        weight_grad<H3, S3, S2>(l.h3, l.h2, H2, g + flat_w_off(F, 2), first);
+        bias_grad<H3, S3>(l.h3, g + flat_b_off(F, 2), first);
         __syncthreads();
-        // ---- layer 1: dW1 = dz1^T h1 (128 x 256), db1; dz0 = (dz1 W1) * d(h1)
-        weight_grad<H2, S2, S1>(l.d2, l.h1, H1, g + flat_w_off(F, 1), first);
-        bias_grad<H2, S2>(l.d2, g + flat_b_off(F, 1), first);
-        input_grad<H2, H1, S2, S1>(l.d2, w + flat_w_off(F, 1), l.h1, sc, l.d1);
+        input_grad<H3, H2, S3, S2>(l.h3, w + flat_w_off(F, 2), l.h2, sc, l.h2);
+        __syncthreads();
+        // ---- layer 1: dW1 = dz1^T h1 (128 x 256), db1; then dz0 = (dz1 W1) * d(h1) replaces h1
+        weight_grad<H2, S2, S1>(l.h2, l.h1, H1, g + flat_w_off(F, 1), first);
+        bias_grad<H2, S2>(l.h2, g + flat_b_off(F, 1), first);
+        __syncthreads();
+        input_grad<H2, H1, S2, S1>(l.h2, w + flat_w_off(F, 1), l.h1, sc, l.h1);
         __syncthreads();
         // ---- layer 0: dW0 = dz0^T x (256 x F), db0
-        weight_grad<H1, S1, SX>(l.d1, l.xs, F, g + flat_w_off(F, 0), first);
-        bias_grad<H1, S1>(l.d1, g + flat_b_off(F, 0), first);
+        weight_grad<H1, S1, SX>(l.h1, l.xs, F, g + flat_w_off(F, 0), first);
+        bias_grad<H1, S1>(l.h1, g + flat_b_off(F, 0), first);
         __syncthreads();
     }
 }
@@ -577,7 +574,7 @@ static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const 
 
 int launch_train_forward(const float* xb, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s) {
-    const size_t lds = kLdsFloatsFwd * sizeof(float);
+    const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_forward_kernel<1> : mask_mode == 2 ? train_forward_kernel<2> : train_forward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));

@@ -134,8 +134,8 @@ class EnsembleTrainer:
         _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed, self.p_drop,
                                           _p(Y), st), "mcmc_train_forward")
         dp = _dp_world(group) > 1
-        if dp:
-            self._dp_loss(Y, yb, rows, delta, group, global_rows)
+        if dp or rows >= 4096:  # large batches: the grid-wide piece-3 kernels instead of one workgroup per member
+            self._dp_loss(Y, yb, rows, delta, group if dp else False, global_rows if dp else rows)
         else:
             _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, self.alpha, self.beta, _p(delta), _p(self.loss), st),
                        "mcmc_train_loss")
@@ -164,7 +164,8 @@ class EnsembleTrainer:
 
     def _dp_loss(self, Y: torch.Tensor, yb: torch.Tensor, rows: int, delta: torch.Tensor, group, global_rows: Optional[int]):
         """peak_weighted_loss with global-batch statistics on the piece-3 kernels (mcmc_loss_*): per member
-        p = mean over samples of this rank's rows; partial sums all-reduced between the passes."""
+        p = mean over samples of this rank's rows; partial sums all-reduced between the passes (group False:
+        single process, no collective - the path large local batches take)."""
         lib, h, st = self.eng.lib, self.eng.ctx.handle, _stream()
         M, S, dev = self.M, self.S, self.eng.device
         rp = (rows + 3) // 4 * 4  # 16-byte aligned member rows
@@ -178,12 +179,14 @@ class EnsembleTrainer:
         stats[:, 3] = rows
         for m in range(M):
             _lib.check(lib.mcmc_loss_stats(h, _p(pbuf[m]), _p(tbuf[m]), rows, _p(stats[m]), st), "mcmc_loss_stats")
-        all_reduce_sum(stats, group)
+        if group is not False:
+            all_reduce_sum(stats, group)
         n_total = int(global_rows) if global_rows is not None else int(round(float(stats[0, 3].item())))
         for m in range(M):
             _lib.check(lib.mcmc_loss_forward(h, _p(pbuf[m]), _p(tbuf[m]), rows, n_total, _p(stats[m]), self.alpha, self.beta,
                                              _p(part[m]), st), "mcmc_loss_forward")
-        all_reduce_sum(part, group)
+        if group is not False:
+            all_reduce_sum(part, group)
         self.loss = (part[:, 0] / n_total).to(torch.float32)
         for m in range(M):
             _lib.check(lib.mcmc_loss_backward(h, _p(pbuf[m]), _p(tbuf[m]), rows, n_total, _p(stats[m]), _p(part[m]), self.alpha,
