@@ -267,13 +267,17 @@ class Engine:
 
     # ---- piece 2 -------------------------------------------------------------------------
     def new_state(self, B: int, nbins: int = 0) -> ReduceState:
-        st = ReduceState(0, torch.zeros(B, dtype=torch.float64, device=self.device),
-                         torch.zeros(B, dtype=torch.float64, device=self.device))
+        """Zeroed per-row partials: one allocation and one fill, viewed as (sum, sumsq[, lo, inv_w, hist])."""
+        Bp = (B + 1) // 2 * 2  # keeps every view 8-byte aligned
+        nbytes = 16 * Bp + (8 * Bp + 2 * B * nbins if nbins else 0)
+        buf = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        f64 = buf[:16 * Bp].view(torch.float64)
+        st = ReduceState(0, f64[:B], f64[Bp:Bp + B])
         if nbins:
             st.nbins = nbins
-            st.hist = torch.zeros(B, nbins, dtype=torch.int16, device=self.device)
-            st.lo = torch.zeros(B, dtype=torch.float32, device=self.device)
-            st.inv_w = torch.zeros(B, dtype=torch.float32, device=self.device)
+            f32 = buf[16 * Bp:24 * Bp].view(torch.float32)
+            st.lo, st.inv_w = f32[:B], f32[Bp:Bp + B]
+            st.hist = buf[24 * Bp:24 * Bp + 2 * B * nbins].view(torch.int16).view(B, nbins)
         return st
 
     def reduce_update(self, Y: torch.Tensor, ldY: int, n_pairs: int, B: int, st: ReduceState, with_hist: bool = True):
