@@ -230,6 +230,34 @@ int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_m
                      float beta1, float beta2, float adam_eps, float weight_decay, float max_norm,
                      int64_t step, float* gnorm, mcmc_stream_t stream);
 
+/* The whole step of bayesian_ensemble.py:165-181 for every member in ONE call: mcmc_train_sample ->
+ * mcmc_train_forward -> mcmc_train_loss -> mcmc_train_backward -> mcmc_train_update on `stream`, for
+ * batches of one row block (mcmc_train_row_blocks(rows) == 1; larger batches and the data-parallel step
+ * use the separate entry points).  xb / yb need not be packed: member m's batch starts at
+ * xb + m*x_member_stride and yb + m*y_member_stride (floats), so a slice [:, b0:b1] of the epoch's
+ * shuffled [M,N,F] / [M,N] tensors (the DataLoader batches of :122-128) is passed in place.
+ * loss_acc: optional fp64 [M]; loss_acc[m] += (double)loss[m] (the epoch_loss of :181), else NULL. */
+typedef struct mcmc_train_buffers {
+    float *mu, *rho, *sigma;    /* [M,P] */
+    float *eps, *W, *WT, *dW;   /* [M*S,P] */
+    float *gmu, *grho;          /* [M,P] */
+    float *adam_m, *adam_v;     /* [M,2P] */
+    double* norm_scratch;       /* [M*mcmc_train_norm_blocks()] */
+    float *Y, *delta;           /* [M*S,rows], [M,rows] */
+    float *loss, *gnorm;        /* [M]; gnorm may be NULL */
+} mcmc_train_buffers;
+typedef struct mcmc_train_hyper {
+    float p_drop, alpha, beta;                           /* dropout (:71), peak_weighted_loss (utils.py:7) */
+    float beta2, adam_eps, weight_decay, max_norm;       /* AdamW (:137-141), clip_grad_norm_ (:179) */
+} mcmc_train_hyper;
+int mcmc_train_step(mcmc_ctx* ctx, const mcmc_train_buffers* buffers, const mcmc_train_hyper* hyper,
+                    const float* xb, int64_t x_member_stride, const float* yb, int64_t y_member_stride,
+                    int64_t rows, int input_dim, int n_members, int n_samples, int noise_mode,
+                    const float* eps_in, uint64_t seed, int mask_mode, const uint8_t* mask0,
+                    const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                    const uint8_t* active, float lr, float beta1, int64_t step, double* loss_acc,
+                    mcmc_stream_t stream);
+
 /* ---- next row: the Temporal Fusion Transformer leg ------------------------ */
 /* models/temporal_fusion.py.  Parameters are ONE flat fp32 vector in the reference module's
  * named_parameters() order (input_projection, feature_grn, temporal_grn, attention, final_grn,

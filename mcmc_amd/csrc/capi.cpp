@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 7; }
+int mcmc_abi_version(void) { return 8; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -309,7 +309,7 @@ int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_d
     if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && WT && Y, "NULL pointer");
-    return launch_train_forward(xb, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y,
+    return launch_train_forward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y,
                                 (hipStream_t)stream);
 }
 
@@ -318,7 +318,7 @@ int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_member
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, 1, rows)) return rc;
     MCMC_REQUIRE(Y && yb && delta && loss, "NULL pointer");
-    return launch_train_loss(Y, yb, n_members, n_samples, rows, alpha, beta, delta, loss, (hipStream_t)stream);
+    return launch_train_loss(Y, yb, rows, n_members, n_samples, rows, alpha, beta, delta, loss, nullptr, (hipStream_t)stream);
 }
 
 static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
@@ -329,7 +329,7 @@ static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && W && WT && delta && dW, "NULL pointer");
     MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
-    return launch_train_backward(xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
+    return launch_train_backward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
                                  delta, row_blocks, dW, (hipStream_t)stream);
 }
 
@@ -384,6 +384,42 @@ int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_m
     MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
     return launch_train_apply(mu, rho, sigma, n_members, input_dim, gmu, grho, adam_m, adam_v, norm_scratch, true, active, lr, beta1,
                               beta2, adam_eps, weight_decay, max_norm, step, gnorm, (hipStream_t)stream);
+}
+
+int mcmc_train_step(mcmc_ctx* ctx, const mcmc_train_buffers* b, const mcmc_train_hyper* hp, const float* xb, int64_t x_member_stride,
+                    const float* yb, int64_t y_member_stride, int64_t rows, int input_dim, int n_members, int n_samples, int noise_mode,
+                    const float* eps_in, uint64_t seed, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
+                    uint64_t mask_seed, const uint8_t* active, float lr, float beta1, int64_t step, double* loss_acc,
+                    mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
+    MCMC_REQUIRE(b && hp, "buffers / hyper is NULL");
+    if (int rc = check_masks(mask_mode, mask0, mask1, mask2, hp->p_drop)) return rc;
+    MCMC_REQUIRE(train_row_blocks(rows) == 1, "mcmc_train_step serves batches of one row block (rows < 2048, got %lld): use the "
+                 "separate mcmc_train_* entry points", (long long)rows);
+    MCMC_REQUIRE(noise_mode >= MCMC_NOISE_NONE && noise_mode <= MCMC_NOISE_PHILOX, "bad noise_mode %d", noise_mode);
+    MCMC_REQUIRE(noise_mode != MCMC_NOISE_INJECTED || eps_in, "MCMC_NOISE_INJECTED needs eps_in");
+    MCMC_REQUIRE(xb && yb, "xb / yb is NULL");
+    MCMC_REQUIRE(x_member_stride >= rows * input_dim && y_member_stride >= rows, "member strides smaller than one member's batch");
+    MCMC_REQUIRE(b->mu && b->rho && b->sigma && b->eps && b->W && b->WT && b->dW && b->gmu && b->grho && b->adam_m && b->adam_v &&
+                 b->norm_scratch && b->Y && b->delta && b->loss, "NULL pointer in mcmc_train_buffers");
+    MCMC_REQUIRE(step >= 1, "step is 1-based");
+    MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && hp->beta2 >= 0.0f && hp->beta2 < 1.0f, "betas must be in [0, 1)");
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = launch_train_sample(b->mu, b->sigma, n_members, n_samples, input_dim, noise_mode, eps_in, seed, b->eps, b->W, b->WT, s))
+        return rc;
+    if (int rc = launch_train_forward(xb, x_member_stride, rows, input_dim, n_members, n_samples, b->WT, mask_mode, mask0, mask1, mask2,
+                                      mask_seed, hp->p_drop, b->Y, s))
+        return rc;
+    if (int rc = launch_train_loss(b->Y, yb, y_member_stride, n_members, n_samples, rows, hp->alpha, hp->beta, b->delta, b->loss,
+                                   loss_acc, s))
+        return rc;
+    if (int rc = launch_train_backward(xb, x_member_stride, rows, input_dim, n_members, n_samples, b->W, b->WT, mask_mode, mask0, mask1,
+                                       mask2, mask_seed, hp->p_drop, b->delta, 1, b->dW, s))
+        return rc;
+    return launch_train_update(b->mu, b->rho, b->sigma, n_members, n_samples, input_dim, b->eps, b->dW, b->gmu, b->grho, b->adam_m,
+                               b->adam_v, b->norm_scratch, active, lr, beta1, hp->beta2, hp->adam_eps, hp->weight_decay, hp->max_norm,
+                               step, b->gnorm, s);
 }
 
 // ---- TFT (row f4) ---------------------------------------------------------------------------------------

@@ -70,11 +70,12 @@ int launch_loss_backward(const mcmc_ctx* ctx, const float* p, const float* t, in
 int launch_train_sigma(const float* rho, float* sigma, int64_t n, hipStream_t s);
 int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F, int noise_mode, const float* eps_in, uint64_t seed,
                         float* eps, float* W, float* WT, hipStream_t s);
-int launch_train_forward(const float* xb, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
+// x_stride / y_stride: floats between consecutive members' batches (rows * F / rows when dense)
+int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s);
-int launch_train_loss(const float* Y, const float* yb, int M, int S, int64_t rows, float alpha, float beta, float* delta, float* loss,
-                      hipStream_t s);
-int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
+int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, int S, int64_t rows, float alpha, float beta, float* delta,
+                      float* loss, double* loss_acc, hipStream_t s);
+int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
                           int row_blocks, float* dW, hipStream_t s);
 int launch_train_grad(int M, int S, int row_blocks, int F, const float* eps, const float* sigma, const float* dW, float* gmu,

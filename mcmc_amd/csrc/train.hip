@@ -301,8 +301,9 @@ __global__ __launch_bounds__(256) void train_sample_kernel(const float* __restri
 
 // T2: train-mode forward, one workgroup per pair ---------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
-                                                              const float* __restrict__ WT, DropMask dm, float* __restrict__ Y) {
+__global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
+                                                              int S, const float* __restrict__ WT, DropMask dm,
+                                                              float* __restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S;
@@ -311,15 +312,16 @@ __global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __res
     const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
     const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
+        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
         __syncthreads();
     }
 }
 
 // T3: pred_mean, peak-weighted loss and d loss / d pred (per sample), one workgroup per member -------
-__global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict__ Y, const float* __restrict__ yb, int S, int64_t rows,
-                                                        float alpha, float beta, float* __restrict__ delta, float* __restrict__ loss) {
+__global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict__ Y, const float* __restrict__ yb, int64_t y_stride, int S,
+                                                        int64_t rows, float alpha, float beta, float* __restrict__ delta,
+                                                        float* __restrict__ loss, double* __restrict__ loss_acc) {
     __shared__ double red[4][NT / 64];
     __shared__ double tot[4];
     const int m = blockIdx.x;
@@ -351,10 +353,10 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
     const double N = (double)rows;
     double v[4] = {0, 0, 0, 0};
     for (int64_t r = threadIdx.x; r < rows; r += NT) {
-        const double t = (double)yb[(int64_t)m * rows + r];
+        const double t = (double)yb[(int64_t)m * y_stride + r];
         v[0] += t;
         v[1] += t * t;
-        v[2] += (double)fabsf(pred(r) - yb[(int64_t)m * rows + r]);
+        v[2] += (double)fabsf(pred(r) - yb[(int64_t)m * y_stride + r]);
     }
     block_sum4(v);
     const double mean_t = v[0] / N;
@@ -363,18 +365,22 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
     const float thr = (float)(mean_t + (double)beta * sd), mean_e = (float)(v[2] / N), am1 = alpha - 1.0f;
     double w2[4] = {0, 0, 0, 0};
     for (int64_t r = threadIdx.x; r < rows; r += NT) {
-        const float t = yb[(int64_t)m * rows + r], d = pred(r) - t;
+        const float t = yb[(int64_t)m * y_stride + r], d = pred(r) - t;
         const float k = t > thr ? 1.0f : 0.0f;
         const float g = 1.0f / (1.0f + expf(mean_e - fabsf(d)));
         w2[0] += (double)(d * d * (1.0f + am1 * k * (1.0f + g)));
         w2[1] += (double)(k * d * d * g * (1.0f - g));
     }
     block_sum4(w2);
-    if (threadIdx.x == 0) loss[m] = (float)(w2[0] / N);
+    if (threadIdx.x == 0) {
+        const float lm = (float)(w2[0] / N);
+        loss[m] = lm;
+        if (loss_acc) loss_acc[m] += (double)lm;  // the epoch sum of bayesian_ensemble.py:181, kept on the device
+    }
     const float g_over_n = (float)(w2[1] / N);
     const float scale = (float)(1.0 / (N * (double)S));  // d pred_mean / d pred_sample = 1/S
     for (int64_t r = threadIdx.x; r < rows; r += NT) {
-        const float t = yb[(int64_t)m * rows + r], d = pred(r) - t;
+        const float t = yb[(int64_t)m * y_stride + r], d = pred(r) - t;
         const float k = t > thr ? 1.0f : 0.0f;
         const float g = 1.0f / (1.0f + expf(mean_e - fabsf(d)));
         const float w = 1.0f + am1 * k * (1.0f + g);
@@ -385,8 +391,8 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
 
 // T4: backward of one pair: recompute the forward tile, then back-propagate -----------------------
 template <int MODE>
-__global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __restrict__ xb, int64_t rows, int F, int S,
-                                                               const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
+__global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
+                                                               int S, const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
                                                                const float* __restrict__ delta, float* __restrict__ dW) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __re
     }
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         const bool first = row_base == begin;
-        forward_tile<MODE>(l, xb + (int64_t)m * rows * F, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
+        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         // ---- layer 3: dw3[k] = sum_r dy[r] h3[r][k], db3 = sum_r dy[r]; dz2 = dy * w3 * d(h3)
         if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
         __syncthreads();
@@ -572,31 +578,31 @@ static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const 
     return dm;
 }
 
-int launch_train_forward(const float* xb, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
+int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_forward_kernel<1> : mask_mode == 2 ? train_forward_kernel<2> : train_forward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(M * S, train_row_blocks(rows)), dim3(NT), lds, s, xb, rows, F, S, WT,
+    hipLaunchKernelGGL(kern, dim3(M * S, train_row_blocks(rows)), dim3(NT), lds, s, xb, x_stride, rows, F, S, WT,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
     return check_launch("train_forward");
 }
 
-int launch_train_loss(const float* Y, const float* yb, int M, int S, int64_t rows, float alpha, float beta, float* delta, float* loss,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(train_loss_kernel, dim3(M), dim3(NT), 0, s, Y, yb, S, rows, alpha, beta, delta, loss);
+int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, int S, int64_t rows, float alpha, float beta, float* delta,
+                      float* loss, double* loss_acc, hipStream_t s) {
+    hipLaunchKernelGGL(train_loss_kernel, dim3(M), dim3(NT), 0, s, Y, yb, y_stride, S, rows, alpha, beta, delta, loss, loss_acc);
     return check_launch("train_loss");
 }
 
-int launch_train_backward(const float* xb, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
+int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
                           int row_blocks, float* dW, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_backward_kernel<1> : mask_mode == 2 ? train_backward_kernel<2> : train_backward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), lds, s, xb, rows, F, S, W, WT,
+    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), lds, s, xb, x_stride, rows, F, S, W, WT,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW);
     return check_launch("train_backward");
 }

@@ -6,6 +6,9 @@ ALL members at once:
 
     train_sample -> train_forward -> train_loss -> train_backward -> train_update (grad + AdamW)
 
+At the reference's batch size the five calls are one (mcmc_train_step), which also takes the batch as
+a strided slice of the epoch's shuffled tensors and keeps the epoch-loss sum on the device.
+
 All arithmetic is in libmcmc_hip.so (include/mcmc_hip.h, mcmc_train_*); torch owns the device
 buffers, the batch gather and - on the host, on a parameter-less dummy optimiser - the
 OneCycleLR schedule, so lr / beta1 per step are the numbers the reference's scheduler produces.
@@ -13,12 +16,13 @@ There is no CPU path.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
-from ._lib import NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX
+from ._lib import NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX, TrainBuffers, TrainHyper
 from .engine import HIDDEN, Engine, _p, _stream, all_reduce_sum, param_count
 
 MASK_NONE, MASK_HOST, MASK_PHILOX = 0, 1, 2
@@ -70,7 +74,8 @@ class EnsembleTrainer:
         self.gnorm = torch.empty(self.M, **f32)
         self.loss = torch.empty(self.M, **f32)
         self.t = 0  # AdamW step count (shared: all members start together; frozen members never resume)
-        self._Y = self._delta = self._dpbuf = None
+        self._Y = self._delta = self._dpbuf = self._bufs = None
+        self._hyper = TrainHyper(p_drop, alpha, beta, beta2, adam_eps, weight_decay, max_norm)
         h = self.eng.ctx.handle
         _lib.check(self.eng.lib.mcmc_train_sigma(h, _p(self.rho), _p(self.sigma), self.rho.numel(), _stream()), "mcmc_train_sigma")
 
@@ -80,10 +85,19 @@ class EnsembleTrainer:
             self._delta = torch.empty(self.M, rows, dtype=torch.float32, device=self.eng.device)
         return self._Y, self._delta
 
+    def _buffers(self) -> TrainBuffers:
+        """mcmc_train_buffers of the current allocations (rebuilt when any tensor was re-allocated or re-bound)."""
+        key = tuple(t.data_ptr() for t in (self.mu, self.rho, self.sigma, self.eps, self.W, self.WT, self.dW, self.gmu, self.grho,
+                                           self.adam_m, self.adam_v, self.norm_scratch, self._Y, self._delta, self.loss, self.gnorm))
+        if self._bufs is None or self._bufs_key != key:
+            self._bufs, self._bufs_key = TrainBuffers(*key), key
+        return self._bufs
+
     def step(self, xb: torch.Tensor, yb: torch.Tensor, lr: float, beta1: float = 0.9, *, noise: str = "philox",
              eps: Optional[torch.Tensor] = None, seed: int = 0, masks: Optional[Sequence[torch.Tensor]] = None,
              mask_seed: Optional[int] = None, dropout: bool = True, active: Optional[torch.Tensor] = None,
-             update: bool = True, group=False, global_rows: Optional[int] = None) -> torch.Tensor:
+             update: bool = True, group=False, global_rows: Optional[int] = None,
+             loss_acc: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One optimisation step of every (active) member.
 
         xb [M,rows,F], yb [M,rows] fp32 on the device.  noise: 'philox' (keyed by ``seed``),
@@ -92,6 +106,8 @@ class EnsembleTrainer:
         (default: seed), or none with dropout=False.  ``active`` [M] uint8 on the device freezes
         members whose flag is 0 (early-stopped; they must not be re-activated later, the AdamW step
         count is shared).  Returns the per-member loss [M] (device tensor, no sync).
+        xb / yb may be slices [:, b0:b1] of [M,N,F] / [M,N] tensors (rows contiguous, any member stride).
+        ``loss_acc``: optional fp64 [M] on the device, loss_acc += loss (the epoch sum of :181).
 
         Data-parallel (BASELINE config 5): with torch.distributed initialised and
         ``group`` None (the default process group) or a group, xb / yb are THIS rank's rows of every
@@ -110,8 +126,12 @@ class EnsembleTrainer:
             raise ValueError(f"yb must be [{M}, {rows}], got {tuple(yb.shape)}")
         if not (xb.is_cuda and yb.is_cuda):
             raise RuntimeError("xb / yb must live on the HIP device; mcmc_amd has no CPU path")
-        xb = xb.to(torch.float32).contiguous()
-        yb = yb.to(torch.float32).contiguous()
+        xb, yb = xb.to(torch.float32), yb.to(torch.float32)
+        if rows == 1 or xb.stride(2) != 1 or xb.stride(1) != F or yb.stride(1) != 1 or xb.stride(0) < rows * F or yb.stride(0) < rows:
+            xb, yb = xb.contiguous(), yb.contiguous()
+        if loss_acc is not None and (loss_acc.dtype != torch.float64 or loss_acc.numel() != M or not loss_acc.is_cuda
+                                     or not loss_acc.is_contiguous()):
+            raise ValueError(f"loss_acc must be a contiguous fp64 [{M}] device tensor")
         noise_mode = {"philox": NOISE_PHILOX, "injected": NOISE_INJECTED, "none": NOISE_NONE}[noise]
         if noise_mode == NOISE_INJECTED:
             if eps is None or eps.numel() != M * S * self.P:
@@ -129,11 +149,20 @@ class EnsembleTrainer:
         mseed = (seed if mask_seed is None else mask_seed) & _U64
         Y, delta = self._work(rows)
         st = _stream()
+        dp = _dp_world(group) > 1
+        if update and not dp and int(lib.mcmc_train_row_blocks(rows)) == 1:  # the reference's batch sizes: one call
+            self.t += 1
+            _lib.check(lib.mcmc_train_step(h, ctypes.byref(self._buffers()), ctypes.byref(self._hyper), xb.data_ptr(), xb.stride(0),
+                                           yb.data_ptr(), yb.stride(0), rows, F, M, S, noise_mode, _p(eps), seed & _U64, mask_mode,
+                                           _p(m0), _p(m1), _p(m2), mseed, _p(active), lr, beta1, self.t, _p(loss_acc), st),
+                       "mcmc_train_step")
+            return self.loss
+        if xb.stride(0) != rows * F or yb.stride(0) != rows:
+            xb, yb = xb.contiguous(), yb.contiguous()
         _lib.check(lib.mcmc_train_sample(h, _p(self.mu), _p(self.sigma), M, S, F, noise_mode, _p(eps), seed & _U64, _p(self.eps),
                                          _p(self.W), _p(self.WT), st), "mcmc_train_sample")
         _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed, self.p_drop,
                                           _p(Y), st), "mcmc_train_forward")
-        dp = _dp_world(group) > 1
         if dp or rows >= 4096:  # large batches: the grid-wide piece-3 kernels instead of one workgroup per member
             self._dp_loss(Y, yb, rows, delta, group if dp else False, global_rows if dp else rows)
         else:
@@ -160,6 +189,8 @@ class EnsembleTrainer:
                                              _p(self.gmu), _p(self.grho), _p(self.adam_m), _p(self.adam_v), _p(self.norm_scratch),
                                              _p(active), lr, beta1, self.beta2, self.adam_eps, self.weight_decay, self.max_norm,
                                              self.t, _p(self.gnorm), st), "mcmc_train_update")
+        if loss_acc is not None:
+            loss_acc += self.loss.double()
         return self.loss
 
     def _dp_loss(self, Y: torch.Tensor, yb: torch.Tensor, rows: int, delta: torch.Tensor, group, global_rows: Optional[int]):
@@ -187,7 +218,7 @@ class EnsembleTrainer:
                                              _p(part[m]), st), "mcmc_loss_forward")
         if group is not False:
             all_reduce_sum(part, group)
-        self.loss = (part[:, 0] / n_total).to(torch.float32)
+        self.loss.copy_(part[:, 0] / n_total)
         for m in range(M):
             _lib.check(lib.mcmc_loss_backward(h, _p(pbuf[m]), _p(tbuf[m]), rows, n_total, _p(stats[m]), _p(part[m]), self.alpha,
                                               self.beta, 1.0 / S, _p(dbuf[m]), st), "mcmc_loss_backward")
@@ -233,14 +264,20 @@ def one_cycle_schedule(epochs: int, steps_per_epoch: int) -> Tuple[List[float], 
 
 
 def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epochs: int = 400, batch_size: int = 32, *,
-                 seed: int = 0, patience: int = 25, log=print, generator: Optional[torch.Generator] = None):
+                 seed: int = 0, patience: int = 25, log=print, generator: Optional[torch.Generator] = None, lookahead: int = 8):
     """The reference's training loop (bayesian_ensemble.py:152-200) for all members at once.
 
     Every member draws its own shuffle of the rows per epoch (the reference builds one shuffling
     DataLoader and iterates it once per member and epoch, :122-128,160), the ragged last batch is kept
     (drop_last=False), epoch losses are summed per member, and a member stops updating after
     ``patience`` epochs without improvement (:185-193) while the others go on.
-    Returns the list of per-member epoch counts actually trained."""
+
+    The stream never drains at an epoch boundary: the early-stopping rule runs on the device (it only has
+    to produce the kernels' ``active`` flags), the epoch losses come back through pinned memory, and the
+    host applies the same rule to the same fp64 numbers up to ``lookahead`` epochs later for the log
+    lines, the epoch counts and the end of the loop.  Epochs queued past the point where every member had
+    stopped update nothing (all members frozen).  Returns the list of per-member epoch counts actually trained."""
+    from collections import deque
     dev = trainer.eng.device
     M = trainer.M
     X = X.rename(None).to(device=dev, dtype=torch.float32)
@@ -248,23 +285,25 @@ def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epo
     N = X.shape[0]
     bounds = [(b, min(b + batch_size, N)) for b in range(0, N, batch_size)]
     lrs, b1s = one_cycle_schedule(epochs, len(bounds))
+    # host copy of the rule: logs, epoch counts, termination
     best = torch.full((M,), float("inf"), dtype=torch.float64)
     bad = torch.zeros(M, dtype=torch.int64)
     alive = torch.ones(M, dtype=torch.bool)
-    active = torch.ones(M, dtype=torch.uint8, device=dev)
     trained = [0] * M
-    it = 0
-    for epoch in range(epochs):
-        # per-member permutation, drawn on the host generator like DataLoader's sampler
-        perm = torch.stack([torch.randperm(N, generator=generator) for _ in range(M)]).to(dev)
-        Xe = X[perm]                      # [M, N, F]
-        ye = y[perm]                      # [M, N]
-        epoch_loss = torch.zeros(M, dtype=torch.float64, device=dev)
-        for (b0, b1) in bounds:
-            loss = trainer.step(Xe[:, b0:b1], ye[:, b0:b1], lrs[it], b1s[it], seed=(seed + _GOLDEN * (it + 1)) & _U64, active=active)
-            epoch_loss += loss.double()
-            it += 1
-        el = epoch_loss.cpu()             # one sync per epoch
+    # device copy of the rule: the active flags of the next epoch's steps
+    d_best = torch.full((M,), float("inf"), dtype=torch.float64, device=dev)
+    d_bad = torch.zeros(M, dtype=torch.int64, device=dev)
+    d_alive = torch.ones(M, dtype=torch.bool, device=dev)
+    d_zero = torch.zeros(M, dtype=torch.int64, device=dev)
+    active = torch.ones(M, dtype=torch.uint8, device=dev)
+    depth = max(0, int(lookahead))
+    slots = depth + 2  # an epoch's pinned slot is re-used only after that epoch has been settled
+    perm_pin = torch.empty(slots, M, N, dtype=torch.int64).pin_memory()
+    loss_pin = torch.empty(slots, M, dtype=torch.float64).pin_memory()
+    pending = deque()  # (epoch, slot, event after the epoch's last copy, AdamW step count after the epoch)
+
+    def settle(epoch: int, el: torch.Tensor) -> bool:
+        """bayesian_ensemble.py:183-200 for one finished epoch; False once no member is left."""
         for m in range(M):
             if not alive[m]:
                 continue
@@ -278,7 +317,42 @@ def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epo
                 log(f"Model {m + 1}/{M}: Early stopping at epoch {epoch}")
             elif (epoch + 1) % 20 == 0:
                 log(f"Model {m + 1}/{M}, Epoch {epoch + 1}/{epochs}, Loss: {float(el[m]):.4f}")
-        if not alive.any():
+        return bool(alive.any())
+
+    def settle_ready(limit: int) -> bool:
+        """Settle epochs whose losses have arrived, and the oldest ones beyond ``limit`` queued epochs."""
+        while pending and (len(pending) > limit or pending[0][2].query()):
+            epoch, slot, ev, t_after = pending.popleft()
+            ev.synchronize()
+            if not settle(epoch, loss_pin[slot]):
+                trainer.t = t_after  # later epochs were queued with every member frozen: they applied no step
+                pending.clear()
+                return False
+        return True
+
+    it = 0
+    for epoch in range(epochs):
+        slot = epoch % slots
+        for m in range(M):  # per-member permutation, drawn on the host generator like DataLoader's sampler
+            torch.randperm(N, generator=generator, out=perm_pin[slot, m])
+        perm = perm_pin[slot].to(dev, non_blocking=True)
+        Xe = X[perm]                      # [M, N, F]
+        ye = y[perm]                      # [M, N]
+        epoch_loss = torch.zeros(M, dtype=torch.float64, device=dev)
+        for (b0, b1) in bounds:
+            trainer.step(Xe[:, b0:b1], ye[:, b0:b1], lrs[it], b1s[it], seed=(seed + _GOLDEN * (it + 1)) & _U64, active=active,
+                         loss_acc=epoch_loss)
+            it += 1
+        improved = epoch_loss < d_best
+        d_best = torch.where(improved, epoch_loss, d_best)
+        d_bad = torch.where(improved, d_zero, d_bad + 1)
+        d_alive = d_alive & (d_bad < patience)
+        active = d_alive.to(torch.uint8)
+        loss_pin[slot].copy_(epoch_loss, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        pending.append((epoch, slot, ev, trainer.t))
+        if not settle_ready(depth):
             break
-        active = alive.to(torch.uint8).to(dev)
+    settle_ready(0)
     return trained

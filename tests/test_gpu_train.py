@@ -181,6 +181,62 @@ def test_fit_ensemble_learns_and_stops_early():
     tr2 = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
     trained2 = fit_ensemble(tr2, X, y, epochs=30, seed=5, patience=1, log=logs.append, generator=torch.Generator().manual_seed(1))
     assert all(1 <= t <= 30 for t in trained2) and any("Early stopping" in s for s in logs)
+    # the look-ahead loop (device-side early stopping, losses settled epochs later) == the epoch-synchronous loop
+    for pat in (1, 3):
+        runs = []
+        for look in (0, 8):
+            t3 = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+            lg = []
+            tr_epochs = fit_ensemble(t3, X, y, epochs=30, seed=5, patience=pat, log=lg.append, generator=torch.Generator().manual_seed(1),
+                                     lookahead=look)
+            runs.append((tr_epochs, lg, t3.t, t3.mu.cpu(), t3.rho.cpu(), t3.adam_v.cpu()))
+        assert runs[0][:3] == runs[1][:3], (runs[0][:3], runs[1][:3])
+        assert all(torch.equal(a, b) for a, b in zip(runs[0][3:], runs[1][3:]))
+
+
+def test_train_step_strided_batches_and_epoch_loss_equal_separate_calls():
+    """mcmc_train_step on slices of the epoch tensors == the five separate entry points on packed copies, bit for bit;
+    loss_acc is the fp64 sum of the per-step fp32 losses (bayesian_ensemble.py:181)."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import _p, _stream
+    from mcmc_amd.train import EnsembleTrainer
+    F, M, S, N = 11, 3, 4, 100
+    mu, rho = _members(F, M, 31)
+    g = torch.Generator().manual_seed(32)
+    Xe = torch.randn(M, N, F, generator=g).to(DEV)
+    ye = torch.randn(M, N, generator=g).to(DEV)
+    fused = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    sep = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    lib, h = sep.eng.lib, sep.eng.ctx.handle
+    acc = torch.zeros(M, dtype=torch.float64, device=DEV)
+    want_acc = torch.zeros(M, dtype=torch.float64)
+    for it, (b0, b1) in enumerate([(0, 32), (32, 64), (64, 96), (96, 100)]):  # ragged last batch like drop_last=False
+        rows, seed, lr, b1m = b1 - b0, 1000 + it, 1e-3 * (it + 1), 0.9 - 0.01 * it
+        loss = fused.step(Xe[:, b0:b1], ye[:, b0:b1], lr, b1m, seed=seed, loss_acc=acc)
+        xb, yb = Xe[:, b0:b1].contiguous(), ye[:, b0:b1].contiguous()
+        Y, delta = sep._work(rows)
+        st = _stream()
+        _lib.check(lib.mcmc_train_sample(h, _p(sep.mu), _p(sep.sigma), M, S, F, 2, _p(None), seed, _p(sep.eps), _p(sep.W), _p(sep.WT), st), "s")
+        _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(sep.WT), 2, _p(None), _p(None), _p(None), seed, 0.1, _p(Y), st), "f")
+        _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, 2.0, 0.5, _p(delta), _p(sep.loss), st), "l")
+        _lib.check(lib.mcmc_train_backward(h, _p(xb), rows, F, M, S, _p(sep.W), _p(sep.WT), 2, _p(None), _p(None), _p(None), seed, 0.1,
+                                           _p(delta), _p(sep.dW), st), "b")
+        _lib.check(lib.mcmc_train_update(h, _p(sep.mu), _p(sep.rho), _p(sep.sigma), M, S, F, _p(sep.eps), _p(sep.dW), _p(sep.gmu),
+                                         _p(sep.grho), _p(sep.adam_m), _p(sep.adam_v), _p(sep.norm_scratch), _p(None), lr, b1m, 0.999,
+                                         1e-8, 0.01, 1.0, it + 1, _p(sep.gnorm), st), "u")
+        assert torch.equal(loss, sep.loss), it
+        want_acc += sep.loss.cpu().double()
+    for name in ("mu", "rho", "sigma", "adam_m", "adam_v", "gnorm"):
+        assert torch.equal(getattr(fused, name), getattr(sep, name)), name
+    assert torch.equal(acc.cpu(), want_acc)
+    # a batch the kernels cannot address in place (row stride != F) is packed by the host side: same numbers
+    wide = torch.zeros(M, 32, F + 3, device=DEV)
+    wide[:, :, :F] = Xe[:, :32]
+    a = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    b = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+    la = a.step(wide[:, :, :F], ye[:, :32], 1e-3, 0.9, seed=5)
+    lb = b.step(Xe[:, :32].contiguous(), ye[:, :32].contiguous(), 1e-3, 0.9, seed=5)
+    assert torch.equal(la, lb) and torch.equal(a.mu, b.mu)
 
 
 def test_train_capi_rejects_bad_arguments():
@@ -198,6 +254,17 @@ def test_train_capi_rejects_bad_arguments():
     assert lib.mcmc_train_sample(h, p, p, 1, 1, 11, 1, z, 0, p, p, p, z) == -1                    # injected without eps
     assert lib.mcmc_train_update(h, p, p, p, 1, 1, 11, p, p, p, p, p, p, p, z, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0, z, z) == -1
     assert b"step" in lib.mcmc_last_error()
+    # mcmc_train_step: NULL structs, a batch of more than one row block, member strides shorter than a batch
+    bufs = _lib.TrainBuffers(*([buf.data_ptr()] * 16))
+    hyp = _lib.TrainHyper(0.1, 2.0, 0.5, 0.999, 1e-8, 0.01, 1.0)
+    args = lambda b, hy, rows, xs, ys: (h, b, hy, p, xs, p, ys, rows, 11, 1, 1, 2, z, 0, 0, z, z, z, 0, z, 1e-3, 0.9, 1, z, z)
+    assert lib.mcmc_train_step(*args(None, C.byref(hyp), 32, 352, 32)) == -1
+    assert lib.mcmc_train_step(*args(C.byref(bufs), C.byref(hyp), 4096, 4096 * 11, 4096)) == -1
+    assert b"row block" in lib.mcmc_last_error()
+    assert lib.mcmc_train_step(*args(C.byref(bufs), C.byref(hyp), 32, 100, 32)) == -1
+    assert b"stride" in lib.mcmc_last_error()
+    bufs.Y = None
+    assert lib.mcmc_train_step(*args(C.byref(bufs), C.byref(hyp), 32, 352, 32)) == -1
 
 
 def test_ensemble_train_then_predict_end_to_end():
