@@ -117,6 +117,14 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # communicator set-up (RCCL connects its rings over xGMI on the first collective of each kind): not part of any
+        # step, so it is done here whatever --warmup says
+        probe = torch.zeros(world, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if backend == "nccl":
+            dist.all_to_all_single(torch.empty_like(probe), probe)
+            dist.all_gather_into_tensor(torch.empty(world * world, device=device), probe)
+            torch.cuda.synchronize()
 
     from mcmc_amd import mc_predict, pack_members
     from mcmc_amd.data import make_series_batch

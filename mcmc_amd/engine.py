@@ -12,6 +12,7 @@ HIP device.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -94,6 +95,16 @@ class ReduceState:
     nbins: int = 0
 
 
+def _single_process(group) -> bool:
+    """No exchange needed: torch.distributed is not initialised or the group has one rank.
+    MCMC_FORCE_COLLECTIVES=1 (test aid) sends a one-rank group through the collectives anyway, so a one-GPU box
+    can exercise the RCCL calls (dtypes, split sizes) of the multi-rank path."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("MCMC_FORCE_COLLECTIVES") != "1"
+
+
 def _via_host(t: torch.Tensor, group) -> bool:
     import torch.distributed as dist
     return t.is_cuda and dist.get_backend(group) == "gloo"
@@ -118,7 +129,7 @@ def combine_partials(state: ReduceState, group=None) -> ReduceState:
     (uint16 pairs viewed as int32: no carry crosses a half while total counts stay <= 65,535).
     RCCL over xGMI when the tensors are on GPUs (backend 'nccl'), gloo on CPU tensors in tests."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single_process(group):
         return state
     moments = torch.stack([state.sum, state.sumsq])
     count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
@@ -148,7 +159,7 @@ def scatter_combine(state: ReduceState, group=None) -> Tuple[ReduceState, int, i
     all ranks by construction: they come from the all-reduced pilot)."""
     import torch.distributed as dist
     B = state.sum.shape[0]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single_process(group):
         return state, 0, B
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = [row_slice(B, r, world)[:2] for r in range(world)]
@@ -185,7 +196,7 @@ def gather_rows(parts: Sequence[Optional[torch.Tensor]], B: int, group=None) -> 
     [B] / [k, B] tensors on every rank: the parts are packed into one [K, per] block so the step is a
     single all_gather_into_tensor."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _single_process(group):
         return list(parts)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     r0, r1, per = row_slice(B, rank, world)

@@ -14,17 +14,30 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_two_ranks_match_single_rank():
+def _run_check(nproc: int, log_name: str, **extra_env):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MCMC_CHECK_TIMEOUT=os.environ.get("MCMC_CHECK_TIMEOUT", "150"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    env = dict(os.environ, MCMC_CHECK_TIMEOUT=os.environ.get("MCMC_CHECK_TIMEOUT", "150"), **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tools", "check_multirank.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):  # keep the ranks' output where a GPU session can read it back
-        with open(os.path.join(out_dir, "multirank_test.log"), "w") as f:
+        with open(os.path.join(out_dir, log_name), "w") as f:
             f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    return r
+
+
+@pytest.mark.gpu
+def test_two_ranks_match_single_rank():
+    r = _run_check(2, "multirank_test.log")
     assert r.returncode == 0 and "multirank OK: world=2" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_collectives():
+    """The RCCL calls of the multi-rank path (byte all-to-all with split sizes, fp64 / int32 all-reduce, all-gather) on a
+    one-rank 'nccl' group, forced through the collectives (MCMC_FORCE_COLLECTIVES=1): what a one-GPU box can run of them."""
+    r = _run_check(1, "rccl_one_rank_test.log", MCMC_FORCE_COLLECTIVES="1")
+    assert r.returncode == 0 and "multirank OK: world=1 backend=nccl" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])

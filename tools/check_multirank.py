@@ -28,6 +28,13 @@ def main():
     dev = torch.device("cuda", local % ngpu)
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def from_rank0(t):
+        """Rank 0's copy of a result, on the host (RCCL moves device tensors, gloo host tensors)."""
+        ref = t.detach().clone() if backend == "nccl" else t.detach().cpu()
+        dist.broadcast(ref, src=0)
+        return ref.cpu()
+
     solo = None
     for r in range(world):  # every rank must take part in every new_group call
         g = dist.new_group([r])
@@ -52,9 +59,7 @@ def main():
         bad = ((shard.quantiles - alone.quantiles).abs() > width)
         assert not bool(bad.any()), (dtype, int(bad.sum()), float(((shard.quantiles - alone.quantiles).abs() / width).max()))
         # all ranks hold the same full result
-        ref = shard.mean.cpu()  # host tensors: also valid when the ranks share one GPU over gloo
-        dist.broadcast(ref, src=0)
-        assert torch.equal(ref, shard.mean.cpu())
+        assert torch.equal(from_rank0(shard.mean), shard.mean.cpu())
     # loss, rows split over ranks, global-batch statistics
     N = 4099
     t = torch.randn(N, generator=g)
@@ -94,9 +99,7 @@ def main():
     for a, b in ((whole.mu, shard.mu), (whole.rho, shard.rho)):
         diff = (a - b).abs()
         assert float((diff <= 2e-6).float().mean()) >= 0.999 and float(diff.max()) <= 2.1 * lr * steps, (float(diff.max()),)
-    ref = shard.mu.cpu()
-    dist.broadcast(ref, src=0)
-    assert torch.equal(ref, shard.mu.cpu())  # every rank applied the same update
+    assert torch.equal(from_rank0(shard.mu), shard.mu.cpu())  # every rank applied the same update
     dist.barrier()
     if rank == 0:
         print(f"multirank OK: world={world} backend={backend} gpus={ngpu}")
