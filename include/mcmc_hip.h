@@ -236,7 +236,12 @@ int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_m
  * use the separate entry points).  xb / yb need not be packed: member m's batch starts at
  * xb + m*x_member_stride and yb + m*y_member_stride (floats), so a slice [:, b0:b1] of the epoch's
  * shuffled [M,N,F] / [M,N] tensors (the DataLoader batches of :122-128) is passed in place.
- * loss_acc: optional fp64 [M]; loss_acc[m] += (double)loss[m] (the epoch_loss of :181), else NULL. */
+ * loss_acc: optional fp64 [M]; loss_acc[m] += (double)loss[m] (the epoch_loss of :181), else NULL.
+ * act: optional scratch of act_floats >= M*S*mcmc_train_act_floats(rows) floats; when given, the forward
+ * kernel leaves each tile's activations there (57.7 KB per pair and 32 rows, L2-resident at the reference's
+ * batch size) and the backward kernel reloads them instead of recomputing the forward pass - the same
+ * numbers, bit for bit (autograd's saved tensors, :178).  NULL or too small: recompute. */
+int64_t mcmc_train_act_floats(int64_t rows);
 typedef struct mcmc_train_buffers {
     float *mu, *rho, *sigma;    /* [M,P] */
     float *eps, *W, *WT, *dW;   /* [M*S,P] */
@@ -245,6 +250,8 @@ typedef struct mcmc_train_buffers {
     double* norm_scratch;       /* [M*mcmc_train_norm_blocks()] */
     float *Y, *delta;           /* [M*S,rows], [M,rows] */
     float *loss, *gnorm;        /* [M]; gnorm may be NULL */
+    float* act;                 /* optional, see above */
+    int64_t act_floats;
 } mcmc_train_buffers;
 typedef struct mcmc_train_hyper {
     float p_drop, alpha, beta;                           /* dropout (:71), peak_weighted_loss (utils.py:7) */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16 = 0, 1
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class MCMCLibraryError(RuntimeError):
@@ -36,7 +36,7 @@ _i64, _i32, _u64, _f32 = C.c_int64, C.c_int, C.c_uint64, C.c_float
 class TrainBuffers(C.Structure):
     """mcmc_train_buffers (include/mcmc_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("mu", "rho", "sigma", "eps", "W", "WT", "dW", "gmu", "grho", "adam_m", "adam_v", "norm_scratch",
-                                          "Y", "delta", "loss", "gnorm")]
+                                          "Y", "delta", "loss", "gnorm", "act")] + [("act_floats", C.c_int64)]
 
 
 class TrainHyper(C.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
                                 _f32, _i64, _ptr, _stream]),
     "mcmc_train_step": (_i32, [_ctx_p, C.POINTER(TrainBuffers), C.POINTER(TrainHyper), _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32,
                                _ptr, _u64, _i32, _ptr, _ptr, _ptr, _u64, _ptr, _f32, _f32, _i64, _ptr, _stream]),
+    "mcmc_train_act_floats": (_i64, [_i64]),
     "mcmc_tft_param_count": (_i64, [_i32]),
     "mcmc_tft_transpose": (_i32, [_ctx_p, _ptr, _ptr, _i32, _stream]),
     "mcmc_tft_forward": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _stream]),

@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 8; }
+int mcmc_abi_version(void) { return 9; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -310,7 +310,7 @@ int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_d
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && WT && Y, "NULL pointer");
     return launch_train_forward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y,
-                                (hipStream_t)stream);
+                                nullptr, (hipStream_t)stream);
 }
 
 int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples, int64_t rows, float alpha,
@@ -330,7 +330,7 @@ static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int
     MCMC_REQUIRE(xb && W && WT && delta && dW, "NULL pointer");
     MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     return launch_train_backward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
-                                 delta, row_blocks, dW, (hipStream_t)stream);
+                                 delta, row_blocks, dW, nullptr, (hipStream_t)stream);
 }
 
 int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
@@ -351,6 +351,8 @@ int mcmc_train_backward_blocks(mcmc_ctx* ctx, const float* xb, int64_t rows, int
 }
 
 int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }
+
+int64_t mcmc_train_act_floats(int64_t rows) { return rows < 1 ? 0 : train_act_floats(rows); }
 
 int mcmc_train_update(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_members, int n_samples, int input_dim,
                       const float* eps, const float* dW, float* gmu, float* grho, float* adam_m, float* adam_v, double* norm_scratch,
@@ -405,17 +407,19 @@ int mcmc_train_step(mcmc_ctx* ctx, const mcmc_train_buffers* b, const mcmc_train
                  b->norm_scratch && b->Y && b->delta && b->loss, "NULL pointer in mcmc_train_buffers");
     MCMC_REQUIRE(step >= 1, "step is 1-based");
     MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && hp->beta2 >= 0.0f && hp->beta2 < 1.0f, "betas must be in [0, 1)");
+    // small batches keep the forward pass's activations for the backward kernel when the caller provides room for them
+    float* act = (b->act && b->act_floats >= (int64_t)n_members * n_samples * train_act_floats(rows)) ? b->act : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (int rc = launch_train_sample(b->mu, b->sigma, n_members, n_samples, input_dim, noise_mode, eps_in, seed, b->eps, b->W, b->WT, s))
         return rc;
     if (int rc = launch_train_forward(xb, x_member_stride, rows, input_dim, n_members, n_samples, b->WT, mask_mode, mask0, mask1, mask2,
-                                      mask_seed, hp->p_drop, b->Y, s))
+                                      mask_seed, hp->p_drop, b->Y, act, s))
         return rc;
     if (int rc = launch_train_loss(b->Y, yb, y_member_stride, n_members, n_samples, rows, hp->alpha, hp->beta, b->delta, b->loss,
                                    loss_acc, s))
         return rc;
     if (int rc = launch_train_backward(xb, x_member_stride, rows, input_dim, n_members, n_samples, b->W, b->WT, mask_mode, mask0, mask1,
-                                       mask2, mask_seed, hp->p_drop, b->delta, 1, b->dW, s))
+                                       mask2, mask_seed, hp->p_drop, b->delta, 1, b->dW, act, s))
         return rc;
     return launch_train_update(b->mu, b->rho, b->sigma, n_members, n_samples, input_dim, b->eps, b->dW, b->gmu, b->grho, b->adam_m,
                                b->adam_v, b->norm_scratch, active, lr, beta1, hp->beta2, hp->adam_eps, hp->weight_decay, hp->max_norm,

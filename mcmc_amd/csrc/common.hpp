@@ -72,12 +72,12 @@ int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F
                         float* eps, float* W, float* WT, hipStream_t s);
 // x_stride / y_stride: floats between consecutive members' batches (rows * F / rows when dense)
 int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
-                         const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s);
+                         const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, float* act, hipStream_t s);
 int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, int S, int64_t rows, float alpha, float beta, float* delta,
                       float* loss, double* loss_acc, hipStream_t s);
 int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                          int row_blocks, float* dW, hipStream_t s);
+                          int row_blocks, float* dW, const float* act, hipStream_t s);
 int launch_train_grad(int M, int S, int row_blocks, int F, const float* eps, const float* sigma, const float* dW, float* gmu,
                       float* grho, double* normsq_part, hipStream_t s);
 int train_row_blocks(int64_t rows);
@@ -88,6 +88,7 @@ int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F
                         float* grho, float* am, float* av, double* normsq_part, const uint8_t* active, float lr, float beta1,
                         float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm, hipStream_t s);
 int train_grad_blocks();
+int64_t train_act_floats(int64_t rows);  // act: [pairs][tiles] saved activations, forward -> backward (nullptr: recompute)
 
 int tft_params(int F);
 int tft_flat_blocks();

@@ -173,6 +173,10 @@ struct Lds {
     float* y;    // [TR] outputs, then dLoss/dy in the backward pass
 };
 constexpr int kLdsFloats = TR * (SX + S1 + S2 + S3 + 1);  // 62 KB: two workgroups per CU, forward and backward
+// h1, h2, h3 of one tile are contiguous in LDS: the forward kernel can save them (57.7 KB per pair and tile) so that
+// the backward kernel of a small batch reloads them from L2 instead of recomputing the tile's forward pass
+constexpr int kActFloats = TR * (S1 + S2 + S3);
+static_assert(kActFloats % 4 == 0 && (TR * SX) % 4 == 0, "activation tiles are copied as float4");
 
 __device__ __forceinline__ Lds carve(float* base) {
     Lds l;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void train_sample_kernel(const float* __restri
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
                                                               int S, const float* __restrict__ WT, DropMask dm,
-                                                              float* __restrict__ Y) {
+                                                              float* __restrict__ Y, float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S;
@@ -314,6 +318,12 @@ __global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __res
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
+        if (act) {  // keep the tile's activations for the backward kernel
+            const int64_t tiles = (rows + TR - 1) / TR;
+            float4* dst = reinterpret_cast<float4*>(act + ((int64_t)pair * tiles + row_base / TR) * kActFloats);
+            const float4* src = reinterpret_cast<const float4*>(l.h1);
+            for (int i = threadIdx.x; i < kActFloats / 4; i += NT) dst[i] = src[i];
+        }
         __syncthreads();
     }
 }
@@ -393,7 +403,8 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
                                                                int S, const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
-                                                               const float* __restrict__ delta, float* __restrict__ dW) {
+                                                               const float* __restrict__ delta, float* __restrict__ dW,
+                                                               const float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S, t = threadIdx.x;
@@ -410,7 +421,20 @@ __global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __re
     }
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         const bool first = row_base == begin;
-        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
+        if (act) {  // the forward kernel saved this tile's activations: reload them (and the input tile)
+            const float* xm = xb + (int64_t)m * x_stride;
+            for (int i = t; i < TR * SX; i += NT) {
+                const int r = i / SX, k = i % SX;
+                l.xs[i] = (row_base + r < rows && k < F) ? xm[(row_base + r) * F + k] : 0.0f;
+            }
+            const int64_t tiles = (rows + TR - 1) / TR;
+            const float4* src = reinterpret_cast<const float4*>(act + ((int64_t)pair * tiles + row_base / TR) * kActFloats);
+            float4* dst = reinterpret_cast<float4*>(l.h1);
+            for (int i = t; i < kActFloats / 4; i += NT) dst[i] = src[i];
+            __syncthreads();
+        } else {
+            forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
+        }
         // ---- layer 3: dw3[k] = sum_r dy[r] h3[r][k], db3 = sum_r dy[r]; dz2 = dy * w3 * d(h3)
         if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
         __syncthreads();
@@ -579,13 +603,13 @@ static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const 
 }
 
 int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
-                         const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, hipStream_t s) {
+                         const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, float* act, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_forward_kernel<1> : mask_mode == 2 ? train_forward_kernel<2> : train_forward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(M * S, train_row_blocks(rows)), dim3(NT), lds, s, xb, x_stride, rows, F, S, WT,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y, act);
     return check_launch("train_forward");
 }
 
@@ -597,13 +621,13 @@ int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, 
 
 int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                          int row_blocks, float* dW, hipStream_t s) {
+                          int row_blocks, float* dW, const float* act, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_backward_kernel<1> : mask_mode == 2 ? train_backward_kernel<2> : train_backward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), lds, s, xb, x_stride, rows, F, S, W, WT,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW);
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, act);
     return check_launch("train_backward");
 }
 
@@ -643,6 +667,9 @@ int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F
 }
 
 int train_grad_blocks() { return kGradBlocks; }
+
+// floats per pair of the saved-activation buffer for a batch of `rows` rows
+int64_t train_act_floats(int64_t rows) { return (rows + TR - 1) / TR * (int64_t)kActFloats; }
 
 // Row blocks a batch of `rows` rows per member is split into (each pair then runs on that many workgroups):
 // one up to 2,047 rows - the reference's 32-row batches - then one per 1,024 rows, at most 64.

@@ -44,6 +44,8 @@ class EnsembleTrainer:
     ``step`` is one pass of bayesian_ensemble.py:165-181 for every member on its own mini-batch.
     Pair index = member * num_samples + sample keys the Philox noise / mask streams."""
 
+    ACT_MAX_ROWS = 128  # batches up to this many rows save their activations for the backward kernel (else: recompute)
+
     def __init__(self, mu: torch.Tensor, rho: torch.Tensor, input_dim: int, num_samples: int = 10, *, p_drop: float = 0.1,
                  weight_decay: float = 0.01, beta2: float = 0.999, adam_eps: float = 1e-8, max_norm: float = 1.0,
                  alpha: float = 2.0, beta: float = 0.5):
@@ -74,7 +76,7 @@ class EnsembleTrainer:
         self.gnorm = torch.empty(self.M, **f32)
         self.loss = torch.empty(self.M, **f32)
         self.t = 0  # AdamW step count (shared: all members start together; frozen members never resume)
-        self._Y = self._delta = self._dpbuf = self._bufs = None
+        self._Y = self._delta = self._dpbuf = self._bufs = self._act = None
         self._hyper = TrainHyper(p_drop, alpha, beta, beta2, adam_eps, weight_decay, max_norm)
         h = self.eng.ctx.handle
         _lib.check(self.eng.lib.mcmc_train_sigma(h, _p(self.rho), _p(self.sigma), self.rho.numel(), _stream()), "mcmc_train_sigma")
@@ -83,12 +85,19 @@ class EnsembleTrainer:
         if self._Y is None or self._Y.shape[1] != rows:
             self._Y = torch.empty(self.M * self.S, rows, dtype=torch.float32, device=self.eng.device)
             self._delta = torch.empty(self.M, rows, dtype=torch.float32, device=self.eng.device)
+            # saved activations for the backward kernel of small batches (the reference's 32 rows: 2.9 MB for 50 pairs)
+            need = self.M * self.S * int(self.eng.lib.mcmc_train_act_floats(rows)) if rows <= self.ACT_MAX_ROWS else 0
+            if need == 0:
+                self._act = None
+            elif self._act is None or self._act.numel() < need:
+                self._act = torch.empty(need, dtype=torch.float32, device=self.eng.device)
         return self._Y, self._delta
 
     def _buffers(self) -> TrainBuffers:
         """mcmc_train_buffers of the current allocations (rebuilt when any tensor was re-allocated or re-bound)."""
         key = tuple(t.data_ptr() for t in (self.mu, self.rho, self.sigma, self.eps, self.W, self.WT, self.dW, self.gmu, self.grho,
                                            self.adam_m, self.adam_v, self.norm_scratch, self._Y, self._delta, self.loss, self.gnorm))
+        key += (self._act.data_ptr(), self._act.numel()) if self._act is not None else (None, 0)
         if self._bufs is None or self._bufs_key != key:
             self._bufs, self._bufs_key = TrainBuffers(*key), key
         return self._bufs
