@@ -231,7 +231,8 @@ int mcmc_train_apply(mcmc_ctx* ctx, float* mu, float* rho, float* sigma, int n_m
                      int64_t step, float* gnorm, mcmc_stream_t stream);
 
 /* The whole step of bayesian_ensemble.py:165-181 for every member in ONE call: mcmc_train_sample ->
- * mcmc_train_forward -> mcmc_train_loss -> mcmc_train_backward -> mcmc_train_update on `stream`, for
+ * mcmc_train_forward -> mcmc_train_loss (run inside the backward kernel: same arithmetic, `delta` is not
+ * written) -> mcmc_train_backward -> mcmc_train_update on `stream`, for
  * batches of one row block (mcmc_train_row_blocks(rows) == 1; larger batches and the data-parallel step
  * use the separate entry points).  xb / yb need not be packed: member m's batch starts at
  * xb + m*x_member_stride and yb + m*y_member_stride (floats), so a slice [:, b0:b1] of the epoch's

@@ -330,7 +330,7 @@ static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int
     MCMC_REQUIRE(xb && W && WT && delta && dW, "NULL pointer");
     MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     return launch_train_backward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
-                                 delta, row_blocks, dW, nullptr, (hipStream_t)stream);
+                                 delta, row_blocks, dW, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
@@ -415,11 +415,10 @@ int mcmc_train_step(mcmc_ctx* ctx, const mcmc_train_buffers* b, const mcmc_train
     if (int rc = launch_train_forward(xb, x_member_stride, rows, input_dim, n_members, n_samples, b->WT, mask_mode, mask0, mask1, mask2,
                                       mask_seed, hp->p_drop, b->Y, act, s))
         return rc;
-    if (int rc = launch_train_loss(b->Y, yb, y_member_stride, n_members, n_samples, rows, hp->alpha, hp->beta, b->delta, b->loss,
-                                   loss_acc, s))
-        return rc;
+    // the loss (train_loss_kernel's arithmetic) runs in the prologue of the backward kernel: one launch fewer
+    const TrainLossFuse fuse{b->Y, yb, y_member_stride, hp->alpha, hp->beta, b->loss, loss_acc};
     if (int rc = launch_train_backward(xb, x_member_stride, rows, input_dim, n_members, n_samples, b->W, b->WT, mask_mode, mask0, mask1,
-                                       mask2, mask_seed, hp->p_drop, b->delta, 1, b->dW, act, s))
+                                       mask2, mask_seed, hp->p_drop, b->delta, 1, b->dW, act, &fuse, s))
         return rc;
     return launch_train_update(b->mu, b->rho, b->sigma, n_members, n_samples, input_dim, b->eps, b->dW, b->gmu, b->grho, b->adam_m,
                                b->adam_v, b->norm_scratch, active, lr, beta1, hp->beta2, hp->adam_eps, hp->weight_decay, hp->max_norm,

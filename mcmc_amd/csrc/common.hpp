@@ -75,9 +75,18 @@ int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, float* act, hipStream_t s);
 int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, int S, int64_t rows, float alpha, float beta, float* delta,
                       float* loss, double* loss_acc, hipStream_t s);
+// fuse != nullptr: the backward kernel computes the loss and dLoss/dy itself from Y / yb (no separate loss launch)
+struct TrainLossFuse {
+    const float* Y;
+    const float* yb;
+    int64_t y_stride;
+    float alpha, beta;
+    float* loss;
+    double* loss_acc;
+};
 int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                          int row_blocks, float* dW, const float* act, hipStream_t s);
+                          int row_blocks, float* dW, const float* act, const TrainLossFuse* fuse, hipStream_t s);
 int launch_train_grad(int M, int S, int row_blocks, int F, const float* eps, const float* sigma, const float* dW, float* gmu,
                       float* grho, double* normsq_part, hipStream_t s);
 int train_row_blocks(int64_t rows);

@@ -328,13 +328,26 @@ __global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __res
     }
 }
 
-// T3: pred_mean, peak-weighted loss and d loss / d pred (per sample), one workgroup per member -------
-__global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict__ Y, const float* __restrict__ yb, int64_t y_stride, int S,
-                                                        int64_t rows, float alpha, float beta, float* __restrict__ delta,
-                                                        float* __restrict__ loss, double* __restrict__ loss_acc) {
+// T3: pred_mean, peak-weighted loss and d loss / d pred (per sample) of one member ---------------------
+// Everything a row's dLoss/dy needs beyond its own (pred, target): the member's global-batch statistics.
+struct LossCoef {
+    float thr, mean_e, am1, g_over_n, scale;
+};
+
+// mean over samples, summed in sample order like torch.mean(0)
+__device__ __forceinline__ float pred_mean(const float* __restrict__ Y, int m, int S, int64_t rows, int64_t r) {
+    float a = 0.0f;
+    for (int s = 0; s < S; ++s) a += Y[((int64_t)m * S + s) * rows + r];
+    return a / (float)S;
+}
+
+// All NT threads of a workgroup: the two reduction passes of utils.py:17-28 over member m's batch.  `write` selects
+// the one workgroup that stores loss[m] (and adds it to the epoch sum) when several compute the same member.
+__device__ __forceinline__ LossCoef member_loss(const float* __restrict__ Y, const float* __restrict__ ym, int m, int S, int64_t rows,
+                                                float alpha, float beta, bool write, float* __restrict__ loss,
+                                                double* __restrict__ loss_acc) {
     __shared__ double red[4][NT / 64];
     __shared__ double tot[4];
-    const int m = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     auto block_sum4 = [&](double (&v)[4]) {
 #pragma unroll
@@ -355,57 +368,86 @@ __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict_
         for (int i = 0; i < 4; ++i) v[i] = tot[i];
         __syncthreads();
     };
-    auto pred = [&](int64_t r) {  // mean over samples, summed in sample order like torch.mean(0)
-        float a = 0.0f;
-        for (int s = 0; s < S; ++s) a += Y[((int64_t)m * S + s) * rows + r];
-        return a / (float)S;
-    };
     const double N = (double)rows;
+    // a thread's first row (its only one at the reference's batch sizes) is loaded once for both passes
+    const bool has0 = threadIdx.x < rows;
+    const float t0 = has0 ? ym[threadIdx.x] : 0.0f, p0 = has0 ? pred_mean(Y, m, S, rows, threadIdx.x) : 0.0f;
+    auto for_rows = [&](auto&& f) {
+        if (has0) f(t0, p0);
+        for (int64_t r = (int64_t)threadIdx.x + NT; r < rows; r += NT) f(ym[r], pred_mean(Y, m, S, rows, r));
+    };
     double v[4] = {0, 0, 0, 0};
-    for (int64_t r = threadIdx.x; r < rows; r += NT) {
-        const double t = (double)yb[(int64_t)m * y_stride + r];
+    for_rows([&](float tf, float p) {
+        const double t = (double)tf;
         v[0] += t;
         v[1] += t * t;
-        v[2] += (double)fabsf(pred(r) - yb[(int64_t)m * y_stride + r]);
-    }
+        v[2] += (double)fabsf(p - tf);
+    });
     block_sum4(v);
     const double mean_t = v[0] / N;
     const double var = (v[1] - v[0] * v[0] / N) / (N - 1.0);
     const double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
-    const float thr = (float)(mean_t + (double)beta * sd), mean_e = (float)(v[2] / N), am1 = alpha - 1.0f;
+    LossCoef c;
+    c.thr = (float)(mean_t + (double)beta * sd);
+    c.mean_e = (float)(v[2] / N);
+    c.am1 = alpha - 1.0f;
     double w2[4] = {0, 0, 0, 0};
-    for (int64_t r = threadIdx.x; r < rows; r += NT) {
-        const float t = yb[(int64_t)m * y_stride + r], d = pred(r) - t;
-        const float k = t > thr ? 1.0f : 0.0f;
-        const float g = 1.0f / (1.0f + expf(mean_e - fabsf(d)));
-        w2[0] += (double)(d * d * (1.0f + am1 * k * (1.0f + g)));
+    for_rows([&](float t, float p) {
+        const float d = p - t;
+        const float k = t > c.thr ? 1.0f : 0.0f;
+        const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
+        w2[0] += (double)(d * d * (1.0f + c.am1 * k * (1.0f + g)));
         w2[1] += (double)(k * d * d * g * (1.0f - g));
-    }
+    });
     block_sum4(w2);
-    if (threadIdx.x == 0) {
+    if (write && threadIdx.x == 0) {
         const float lm = (float)(w2[0] / N);
         loss[m] = lm;
         if (loss_acc) loss_acc[m] += (double)lm;  // the epoch sum of bayesian_ensemble.py:181, kept on the device
     }
-    const float g_over_n = (float)(w2[1] / N);
-    const float scale = (float)(1.0 / (N * (double)S));  // d pred_mean / d pred_sample = 1/S
-    for (int64_t r = threadIdx.x; r < rows; r += NT) {
-        const float t = yb[(int64_t)m * y_stride + r], d = pred(r) - t;
-        const float k = t > thr ? 1.0f : 0.0f;
-        const float g = 1.0f / (1.0f + expf(mean_e - fabsf(d)));
-        const float w = 1.0f + am1 * k * (1.0f + g);
-        const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-        delta[(int64_t)m * rows + r] = scale * (2.0f * d * w + am1 * sgn * (k * d * d * g * (1.0f - g) - g_over_n));
-    }
+    c.g_over_n = (float)(w2[1] / N);
+    c.scale = (float)(1.0 / (N * (double)S));  // d pred_mean / d pred_sample = 1/S
+    return c;
 }
 
-// T4: backward of one pair: recompute the forward tile, then back-propagate -----------------------
+// dLoss / d(one sample's prediction) of a row with sample-mean prediction p and target t
+__device__ __forceinline__ float loss_delta(const LossCoef& c, float p, float t) {
+    const float d = p - t;
+    const float k = t > c.thr ? 1.0f : 0.0f;
+    const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
+    const float w = 1.0f + c.am1 * k * (1.0f + g);
+    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return c.scale * (2.0f * d * w + c.am1 * sgn * (k * d * d * g * (1.0f - g) - c.g_over_n));
+}
+
+__global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict__ Y, const float* __restrict__ yb, int64_t y_stride, int S,
+                                                        int64_t rows, float alpha, float beta, float* __restrict__ delta,
+                                                        float* __restrict__ loss, double* __restrict__ loss_acc) {
+    const int m = blockIdx.x;
+    const float* ym = yb + (int64_t)m * y_stride;
+    const LossCoef c = member_loss(Y, ym, m, S, rows, alpha, beta, true, loss, loss_acc);
+    for (int64_t r = threadIdx.x; r < rows; r += NT) delta[(int64_t)m * rows + r] = loss_delta(c, pred_mean(Y, m, S, rows, r), ym[r]);
+}
+
+// T4: backward of one pair: recompute (or reload) the forward tile, then back-propagate ----------------
+// With LossFuse::Y set, the kernel derives dLoss/dy itself: every workgroup of a member repeats the member's two
+// loss reductions (a few microseconds at the reference's batch size) instead of waiting for a separate loss launch.
+struct LossFuse {
+    const float* Y;   // [M*S, rows] predictions of the forward kernel, or nullptr: read `delta`
+    const float* yb;  // targets, member stride y_stride
+    int64_t y_stride;
+    float alpha, beta;
+    float* loss;       // [M]
+    double* loss_acc;  // optional [M]
+};
+
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
                                                                int S, const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
                                                                const float* __restrict__ delta, float* __restrict__ dW,
-                                                               const float* __restrict__ act) {
+                                                               const float* __restrict__ act, LossFuse lf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ LossCoef lcs;
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S, t = threadIdx.x;
     const int64_t P = flat_param_count(F);
@@ -418,6 +460,12 @@ __global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __re
     if (begin >= end) {  // more blocks than tiles: this partial is zero
         for (int64_t i = t; i < P; i += NT) g[i] = 0.0f;
         return;
+    }
+    const float* ym = lf.Y ? lf.yb + (int64_t)m * lf.y_stride : nullptr;
+    if (lf.Y) {
+        const LossCoef c = member_loss(lf.Y, ym, m, S, rows, lf.alpha, lf.beta, pair % S == 0 && blockIdx.y == 0, lf.loss, lf.loss_acc);
+        if (t == 0) lcs = c;  // kept in LDS: the back-propagation below has no registers to spare
+        __syncthreads();
     }
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         const bool first = row_base == begin;
@@ -436,7 +484,12 @@ __global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __re
             forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
         }
         // ---- layer 3: dw3[k] = sum_r dy[r] h3[r][k], db3 = sum_r dy[r]; dz2 = dy * w3 * d(h3)
-        if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
+        if (t < TR) {
+            const int64_t row = row_base + t;
+            float dy = 0.0f;
+            if (row < rows) dy = lf.Y ? loss_delta(lcs, pred_mean(lf.Y, m, S, rows, row), ym[row]) : delta[(int64_t)m * rows + row];
+            l.y[t] = dy;
+        }
         __syncthreads();
         if (t < H3) {
             float a = 0.0f;
@@ -621,13 +674,15 @@ int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, 
 
 int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                          int row_blocks, float* dW, const float* act, hipStream_t s) {
+                          int row_blocks, float* dW, const float* act, const TrainLossFuse* fuse, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     auto kern = mask_mode == 1 ? train_backward_kernel<1> : mask_mode == 2 ? train_backward_kernel<2> : train_backward_kernel<0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
+    LossFuse lf{};
+    if (fuse) lf = LossFuse{fuse->Y, fuse->yb, fuse->y_stride, fuse->alpha, fuse->beta, fuse->loss, fuse->loss_acc};
     hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), lds, s, xb, x_stride, rows, F, S, W, WT,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, act);
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, act, lf);
     return check_launch("train_backward");
 }
 
