@@ -8,8 +8,8 @@
 //   backward through the reparameterisation (dmu = dW, drho = dW * eps * exp(rho)),
 //   clip_grad_norm_(1.0) (:179), AdamW step (:180; lr / beta1 come from the host's OneCycleLR).
 //
-// The batch is 32 rows (:124), so every GEMM here is one or a few 32x32 MFMA tiles.  One workgroup (4 waves)
-// owns one (member, sample) pair and keeps the activations of a 32-row tile in LDS ([row][feature] tiles with
+// The batch is 32 rows (:124), so every GEMM here is one or a few 32x32 MFMA tiles.  One workgroup (4 or 8 waves,
+// train_tiles.hpp) owns one (member, sample) pair and keeps the activations of a 32-row tile in LDS ([row][feature] tiles with
 // odd strides, 62 KB: two workgroups per CU; the backward pass turns them into gradients in place); the weights stream from L2 in two pre-sampled layouts
 // (WT [in][out] for the forward, W [out][in] for the input gradients) as MFMA A operands, 32 consecutive
 // floats per lane half.  All GEMMs run on v_mfma_f32_32x32x2_f32: exact fp32 FMAs, so the step stays
@@ -22,8 +22,6 @@ namespace mcmc {
 namespace {
 
 constexpr int TR = 32;         // rows per LDS tile
-constexpr int NT = 256;        // threads per workgroup (4 waves)
-constexpr int NW = NT / 64;
 // LDS row strides of the [row][feature] tiles: odd, so a column read (32 rows of one feature: the MFMA's B
 // operand) and a row read (32 consecutive features: its A operand) are both bank-conflict-free
 constexpr int SX = 33, S1 = H1 + 1, S2 = H2 + 1, S3 = H3 + 1;
@@ -43,126 +41,10 @@ __device__ __forceinline__ float elu_neg(float z) {
     return um1 == -1.0f ? -1.0f : r;           // exp underflowed
 }
 
-// ---- dense layers on LDS tiles, MFMA ---------------------------------------------------------------
-// Z^T[out, row] = b[out] + sum_k WT[k][out] * hin[row][k]; then h = elu(z) * mask * scale -> hout[row][out].
-// A comes straight from the pre-sampled WT image in global memory / L2 (32 consecutive floats per lane half),
-// B from the LDS tile.  Wave w owns output tiles w, w+4, ...  Masked elements and padding rows are stored as
-// -0.0f: arithmetic zero, and recognisable in the backward pass.
-template <int MODE, int OUT, int IN_STRIDE, int OUT_STRIDE>
-__device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int K, const float* __restrict__ WT,
-                                              const float* __restrict__ bias, float* __restrict__ hout, const DropMask& dm, int pair,
-                                              int64_t rows, int64_t row_base, int layer) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const bool live = row_base + r < rows;
-#pragma unroll 1
-    for (int mo = wave; mo < OUT / 32; mo += NW) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = bias[32 * mo + acc_feature(i, h)];
-        const float* a = WT + 32 * mo + r;
-        const float* b = hin + r * IN_STRIDE;
-        // every weight is used once per tile, so the A stream is bound by L2 latency: issue a batch of loads,
-        // then the MFMAs that consume them
-        if (K % 32) {  // layer 0: K = input width (<= kMaxInputDim), possibly odd; xs columns >= K are zero
-            float av[(kMaxInputDim + 1) / 2], bv[(kMaxInputDim + 1) / 2];
-#pragma unroll
-            for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st) {
-                const int k = 2 * st + h;
-                av[st] = k < K ? a[k * OUT] : 0.0f;
-                bv[st] = b[k];
-            }
-#pragma unroll
-            for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st)
-                if (2 * st < K) acc = mfma2(av[st], bv[st], acc);
-        } else {
-#pragma unroll 1
-            for (int s0 = 0; s0 < K / 2; s0 += 32) {
-                float av[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) av[u] = a[(2 * (s0 + u) + h) * OUT];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) acc = mfma2(av[u], b[2 * (s0 + u) + h], acc);
-            }
-        }
-        float o[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = acc[i] > 0.0f ? acc[i] : elu_neg(acc[i]);
-        drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row_base + r);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) hout[r * OUT_STRIDE + 32 * mo + acc_feature(i, h)] = live ? o[i] : -0.0f;
-    }
-}
-
 // derivative factor d = elu'(z) * mask * scale recovered from the stored activation
 __device__ __forceinline__ float dfactor(float h, float scale) {
     if (__float_as_uint(h) == 0x80000000u) return 0.0f;  // masked (or padding row)
     return h > 0.0f ? scale : h + scale;                 // z > 0: scale;  z <= 0: exp(z)*scale = h + scale
-}
-
-// dW[out][in] (+)= sum_r dz[r][out] * hin[r][in] for one 32-row tile: both operands are row reads of LDS tiles.
-template <int OUT, int DZ_STRIDE, int IN_STRIDE>
-__device__ __forceinline__ void weight_grad(const float* __restrict__ dz, const float* __restrict__ hin, int IN, float* __restrict__ g,
-                                            bool first) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const int n_in = (IN + 31) / 32;
-#pragma unroll 1
-    for (int tile = wave; tile < (OUT / 32) * n_in; tile += NW) {
-        const int mo = tile / n_in, ni = tile % n_in;
-        f32x16 acc = {0};
-        const float* a = dz + 32 * mo + r;
-        const float* b = hin + 32 * ni + r;
-        const int in = 32 * ni + r;
-        // later tiles of a row block accumulate: the running sums are fetched before the MFMA chain and added
-        // after it, so their L2 round trip hides behind the chain
-        float prev[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) prev[i] = (!first && in < IN) ? g[(int64_t)(32 * mo + acc_feature(i, h)) * IN + in] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < TR; k += 2) acc = mfma2(a[(k + h) * DZ_STRIDE], b[(k + h) * IN_STRIDE], acc);
-        if (in < IN) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) g[(int64_t)(32 * mo + acc_feature(i, h)) * IN + in] = prev[i] + acc[i];
-        }
-    }
-}
-
-// db[o] (+)= sum_r dz[r][o]
-template <int OUT, int DZ_STRIDE>
-__device__ __forceinline__ void bias_grad(const float* __restrict__ dz, float* __restrict__ g, bool first) {
-    for (int o = threadIdx.x; o < OUT; o += NT) {
-        float a = 0.0f;
-#pragma unroll
-        for (int r = 0; r < TR; ++r) a += dz[r * DZ_STRIDE + o];
-        g[o] = first ? a : g[o] + a;
-    }
-}
-
-// dzin[r][in] = (sum_o dz[r][o] * W[o][in]) * d(hin[r][in]): A = rows of W [out][in] from global memory / L2,
-// B = columns of the dz tile.
-// dzin may be hin itself: every element is read (for d(.)) and then written by the same lane.
-template <int OUT, int IN, int DZ_STRIDE, int IN_STRIDE>
-__device__ __forceinline__ void input_grad(const float* __restrict__ dz, const float* __restrict__ W, const float* hin, float scale,
-                                           float* dzin) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int mi = wave; mi < IN / 32; mi += NW) {
-        f32x16 acc = {0};
-        const float* a = W + 32 * mi + r;
-        const float* b = dz + r * DZ_STRIDE;
-#pragma unroll 1
-        for (int s0 = 0; s0 < OUT / 2; s0 += 32) {
-            float av[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) av[u] = a[(2 * (s0 + u) + h) * IN];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) acc = mfma2(av[u], b[2 * (s0 + u) + h], acc);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int in = 32 * mi + acc_feature(i, h);
-            dzin[r * IN_STRIDE + in] = acc[i] * dfactor(hin[r * IN_STRIDE + in], scale);
-        }
-    }
 }
 
 struct Lds {
@@ -188,35 +70,55 @@ __device__ __forceinline__ Lds carve(float* base) {
     return l;
 }
 
-// forward of one 32-row tile of one pair; fills xs, h1, h2, h3, y
-template <int MODE>
-__device__ __forceinline__ void forward_tile(const Lds& l, const float* __restrict__ xb, int64_t rows, int F, int64_t row_base,
-                                             const float* __restrict__ WT, const DropMask& dm, int pair) {
-    for (int i = threadIdx.x; i < TR * SX; i += NT) {
-        const int r = i / SX, k = i % SX;
-        l.xs[i] = (row_base + r < rows && k < F) ? xb[(row_base + r) * F + k] : 0.0f;
-    }
-    __syncthreads();
-    // layer 0: k runs over the F real columns only (the next flat entry after W0^T is the bias, never read as a weight)
-    dense_forward<MODE, H1, SX, S1>(l.xs, F, WT + flat_w_off(F, 0), WT + flat_b_off(F, 0), l.h1, dm, pair, rows, row_base, 0);
-    __syncthreads();
-    dense_forward<MODE, H2, S1, S2>(l.h1, H1, WT + flat_w_off(F, 1), WT + flat_b_off(F, 1), l.h2, dm, pair, rows, row_base, 1);
-    __syncthreads();
-    dense_forward<MODE, H3, S2, S3>(l.h2, H2, WT + flat_w_off(F, 2), WT + flat_b_off(F, 2), l.h3, dm, pair, rows, row_base, 2);
-    __syncthreads();
-    {  // layer 3: 64 -> 1; 8 threads per row
-        const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
-        const float* w3 = WT + flat_w_off(F, 3);
-        float a = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a = fmaf(l.h3[r * S3 + part * 8 + k], w3[part * 8 + k], a);
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        a += __shfl_xor(a, 4);
-        if (part == 0) l.y[r] = a + WT[flat_b_off(F, 3)];
-    }
-    __syncthreads();
+// T3: pred_mean, peak-weighted loss and d loss / d pred (per sample) of one member ---------------------
+// Everything a row's dLoss/dy needs beyond its own (pred, target): the member's global-batch statistics.
+struct LossCoef {
+    float thr, mean_e, am1, g_over_n, scale;
+};
+
+// mean over samples, summed in sample order like torch.mean(0)
+__device__ __forceinline__ float pred_mean(const float* __restrict__ Y, int m, int S, int64_t rows, int64_t r) {
+    float a = 0.0f;
+    for (int s = 0; s < S; ++s) a += Y[((int64_t)m * S + s) * rows + r];
+    return a / (float)S;
 }
+
+// dLoss / d(one sample's prediction) of a row with sample-mean prediction p and target t
+__device__ __forceinline__ float loss_delta(const LossCoef& c, float p, float t) {
+    const float d = p - t;
+    const float k = t > c.thr ? 1.0f : 0.0f;
+    const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
+    const float w = 1.0f + c.am1 * k * (1.0f + g);
+    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return c.scale * (2.0f * d * w + c.am1 * sgn * (k * d * d * g * (1.0f - g) - c.g_over_n));
+}
+
+// T4: backward of one pair: recompute (or reload) the forward tile, then back-propagate ----------------
+// With LossFuse::Y set, the kernel derives dLoss/dy itself: every workgroup of a member repeats the member's two
+// loss reductions (a few microseconds at the reference's batch size) instead of waiting for a separate loss launch.
+struct LossFuse {
+    const float* Y;   // [M*S, rows] predictions of the forward kernel, or nullptr: read `delta`
+    const float* yb;  // targets, member stride y_stride
+    int64_t y_stride;
+    float alpha, beta;
+    float* loss;       // [M]
+    double* loss_acc;  // optional [M]
+};
+
+// The tile code is compiled for two workgroup sizes (train_tiles.hpp): four waves, two workgroups per CU, when a
+// launch has more workgroups than the chip has CUs (large batches); eight waves when every workgroup has a CU to
+// itself (the reference's batch sizes: 50 pairs), where the second wave per SIMD hides the first one's L2 latency.
+#define MCMC_TRAIN_NT 256
+namespace nt256 {
+#include "train_tiles.hpp"
+}
+#undef MCMC_TRAIN_NT
+#define MCMC_TRAIN_NT 512
+namespace nt512 {
+#include "train_tiles.hpp"
+}
+#undef MCMC_TRAIN_NT
+constexpr int kWideMaxWorkgroups = 256;  // CUs of an MI355X
 
 // T1: eps, effective weights in both layouts ------------------------------------------------------
 // One workgroup = one 32 x 32 tile of one layer's weight matrix of one pair (or the biases + output layer):
@@ -303,232 +205,6 @@ __global__ __launch_bounds__(256) void train_sample_kernel(const float* __restri
     }
 }
 
-// T2: train-mode forward, one workgroup per pair ---------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(NT, 2) void train_forward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
-                                                              int S, const float* __restrict__ WT, DropMask dm,
-                                                              float* __restrict__ Y, float* __restrict__ act) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const Lds l = carve(smem);
-    const int pair = blockIdx.x, m = pair / S;
-    const int64_t P = flat_param_count(F);
-    // rows of a large batch are split over blockIdx.y in runs of whole tiles
-    const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
-    const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
-    for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
-        if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
-        if (act) {  // keep the tile's activations for the backward kernel
-            const int64_t tiles = (rows + TR - 1) / TR;
-            float4* dst = reinterpret_cast<float4*>(act + ((int64_t)pair * tiles + row_base / TR) * kActFloats);
-            const float4* src = reinterpret_cast<const float4*>(l.h1);
-            for (int i = threadIdx.x; i < kActFloats / 4; i += NT) dst[i] = src[i];
-        }
-        __syncthreads();
-    }
-}
-
-// T3: pred_mean, peak-weighted loss and d loss / d pred (per sample) of one member ---------------------
-// Everything a row's dLoss/dy needs beyond its own (pred, target): the member's global-batch statistics.
-struct LossCoef {
-    float thr, mean_e, am1, g_over_n, scale;
-};
-
-// mean over samples, summed in sample order like torch.mean(0)
-__device__ __forceinline__ float pred_mean(const float* __restrict__ Y, int m, int S, int64_t rows, int64_t r) {
-    float a = 0.0f;
-    for (int s = 0; s < S; ++s) a += Y[((int64_t)m * S + s) * rows + r];
-    return a / (float)S;
-}
-
-// All NT threads of a workgroup: the two reduction passes of utils.py:17-28 over member m's batch.  `write` selects
-// the one workgroup that stores loss[m] (and adds it to the epoch sum) when several compute the same member.
-__device__ __forceinline__ LossCoef member_loss(const float* __restrict__ Y, const float* __restrict__ ym, int m, int S, int64_t rows,
-                                                float alpha, float beta, bool write, float* __restrict__ loss,
-                                                double* __restrict__ loss_acc) {
-    __shared__ double red[4][NT / 64];
-    __shared__ double tot[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto block_sum4 = [&](double (&v)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double x = v[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if (lane == 0) red[i][wave] = x;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            double a = 0.0;
-            for (int w = 0; w < NT / 64; ++w) a += red[threadIdx.x][w];
-            tot[threadIdx.x] = a;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = tot[i];
-        __syncthreads();
-    };
-    const double N = (double)rows;
-    // a thread's first row (its only one at the reference's batch sizes) is loaded once for both passes
-    const bool has0 = threadIdx.x < rows;
-    const float t0 = has0 ? ym[threadIdx.x] : 0.0f, p0 = has0 ? pred_mean(Y, m, S, rows, threadIdx.x) : 0.0f;
-    auto for_rows = [&](auto&& f) {
-        if (has0) f(t0, p0);
-        for (int64_t r = (int64_t)threadIdx.x + NT; r < rows; r += NT) f(ym[r], pred_mean(Y, m, S, rows, r));
-    };
-    double v[4] = {0, 0, 0, 0};
-    for_rows([&](float tf, float p) {
-        const double t = (double)tf;
-        v[0] += t;
-        v[1] += t * t;
-        v[2] += (double)fabsf(p - tf);
-    });
-    block_sum4(v);
-    const double mean_t = v[0] / N;
-    const double var = (v[1] - v[0] * v[0] / N) / (N - 1.0);
-    const double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
-    LossCoef c;
-    c.thr = (float)(mean_t + (double)beta * sd);
-    c.mean_e = (float)(v[2] / N);
-    c.am1 = alpha - 1.0f;
-    double w2[4] = {0, 0, 0, 0};
-    for_rows([&](float t, float p) {
-        const float d = p - t;
-        const float k = t > c.thr ? 1.0f : 0.0f;
-        const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
-        w2[0] += (double)(d * d * (1.0f + c.am1 * k * (1.0f + g)));
-        w2[1] += (double)(k * d * d * g * (1.0f - g));
-    });
-    block_sum4(w2);
-    if (write && threadIdx.x == 0) {
-        const float lm = (float)(w2[0] / N);
-        loss[m] = lm;
-        if (loss_acc) loss_acc[m] += (double)lm;  // the epoch sum of bayesian_ensemble.py:181, kept on the device
-    }
-    c.g_over_n = (float)(w2[1] / N);
-    c.scale = (float)(1.0 / (N * (double)S));  // d pred_mean / d pred_sample = 1/S
-    return c;
-}
-
-// dLoss / d(one sample's prediction) of a row with sample-mean prediction p and target t
-__device__ __forceinline__ float loss_delta(const LossCoef& c, float p, float t) {
-    const float d = p - t;
-    const float k = t > c.thr ? 1.0f : 0.0f;
-    const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
-    const float w = 1.0f + c.am1 * k * (1.0f + g);
-    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    return c.scale * (2.0f * d * w + c.am1 * sgn * (k * d * d * g * (1.0f - g) - c.g_over_n));
-}
-
-__global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict__ Y, const float* __restrict__ yb, int64_t y_stride, int S,
-                                                        int64_t rows, float alpha, float beta, float* __restrict__ delta,
-                                                        float* __restrict__ loss, double* __restrict__ loss_acc) {
-    const int m = blockIdx.x;
-    const float* ym = yb + (int64_t)m * y_stride;
-    const LossCoef c = member_loss(Y, ym, m, S, rows, alpha, beta, true, loss, loss_acc);
-    for (int64_t r = threadIdx.x; r < rows; r += NT) delta[(int64_t)m * rows + r] = loss_delta(c, pred_mean(Y, m, S, rows, r), ym[r]);
-}
-
-// T4: backward of one pair: recompute (or reload) the forward tile, then back-propagate ----------------
-// With LossFuse::Y set, the kernel derives dLoss/dy itself: every workgroup of a member repeats the member's two
-// loss reductions (a few microseconds at the reference's batch size) instead of waiting for a separate loss launch.
-struct LossFuse {
-    const float* Y;   // [M*S, rows] predictions of the forward kernel, or nullptr: read `delta`
-    const float* yb;  // targets, member stride y_stride
-    int64_t y_stride;
-    float alpha, beta;
-    float* loss;       // [M]
-    double* loss_acc;  // optional [M]
-};
-
-template <int MODE>
-__global__ __launch_bounds__(NT, 2) void train_backward_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F,
-                                                               int S, const float* __restrict__ W, const float* __restrict__ WT, DropMask dm,
-                                                               const float* __restrict__ delta, float* __restrict__ dW,
-                                                               const float* __restrict__ act, LossFuse lf) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ LossCoef lcs;
-    const Lds l = carve(smem);
-    const int pair = blockIdx.x, m = pair / S, t = threadIdx.x;
-    const int64_t P = flat_param_count(F);
-    const float* w = W + (int64_t)pair * P;
-    // row block blockIdx.y accumulates its own partial dW[pair * row_blocks + block] (summed by train_grad_kernel)
-    float* g = dW + ((int64_t)pair * gridDim.y + blockIdx.y) * P;
-    const float sc = MODE != 0 ? dm.scale : 1.0f;
-    const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
-    const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
-    if (begin >= end) {  // more blocks than tiles: this partial is zero
-        for (int64_t i = t; i < P; i += NT) g[i] = 0.0f;
-        return;
-    }
-    const float* ym = lf.Y ? lf.yb + (int64_t)m * lf.y_stride : nullptr;
-    if (lf.Y) {
-        const LossCoef c = member_loss(lf.Y, ym, m, S, rows, lf.alpha, lf.beta, pair % S == 0 && blockIdx.y == 0, lf.loss, lf.loss_acc);
-        if (t == 0) lcs = c;  // kept in LDS: the back-propagation below has no registers to spare
-        __syncthreads();
-    }
-    for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        const bool first = row_base == begin;
-        if (act) {  // the forward kernel saved this tile's activations: reload them (and the input tile)
-            const float* xm = xb + (int64_t)m * x_stride;
-            for (int i = t; i < TR * SX; i += NT) {
-                const int r = i / SX, k = i % SX;
-                l.xs[i] = (row_base + r < rows && k < F) ? xm[(row_base + r) * F + k] : 0.0f;
-            }
-            const int64_t tiles = (rows + TR - 1) / TR;
-            const float4* src = reinterpret_cast<const float4*>(act + ((int64_t)pair * tiles + row_base / TR) * kActFloats);
-            float4* dst = reinterpret_cast<float4*>(l.h1);
-            for (int i = t; i < kActFloats / 4; i += NT) dst[i] = src[i];
-            __syncthreads();
-        } else {
-            forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
-        }
-        // ---- layer 3: dw3[k] = sum_r dy[r] h3[r][k], db3 = sum_r dy[r]; dz2 = dy * w3 * d(h3)
-        if (t < TR) {
-            const int64_t row = row_base + t;
-            float dy = 0.0f;
-            if (row < rows) dy = lf.Y ? loss_delta(lcs, pred_mean(lf.Y, m, S, rows, row), ym[row]) : delta[(int64_t)m * rows + row];
-            l.y[t] = dy;
-        }
-        __syncthreads();
-        if (t < H3) {
-            float a = 0.0f;
-#pragma unroll
-            for (int r = 0; r < TR; ++r) a = fmaf(l.y[r], l.h3[r * S3 + t], a);
-            float* p = g + flat_w_off(F, 3) + t;
-            *p = first ? a : *p + a;
-        } else if (t == H3) {
-            float a = 0.0f;
-#pragma unroll
-            for (int r = 0; r < TR; ++r) a += l.y[r];
-            float* p = g + flat_b_off(F, 3);
-            *p = first ? a : *p + a;
-        }
-        __syncthreads();  // dw3 has read h3: dz2 may now replace it
-        for (int i = t; i < TR * H3; i += NT) {
-            const int r = i / H3, k = i % H3;
-            l.h3[r * S3 + k] = l.y[r] * w[flat_w_off(F, 3) + k] * dfactor(l.h3[r * S3 + k], sc);
-        }
-        __syncthreads();
-        // ---- layer 2: dW2 = dz2^T h2 (64 x 128), db2; then dz1 = (dz2 W2) * d(h2) replaces h2
-        weight_grad<H3, S3, S2>(l.h3, l.h2, H2, g + flat_w_off(F, 2), first);
-        bias_grad<H3, S3>(l.h3, g + flat_b_off(F, 2), first);
-        __syncthreads();
-        input_grad<H3, H2, S3, S2>(l.h3, w + flat_w_off(F, 2), l.h2, sc, l.h2);
-        __syncthreads();
-        // ---- layer 1: dW1 = dz1^T h1 (128 x 256), db1; then dz0 = (dz1 W1) * d(h1) replaces h1
-        weight_grad<H2, S2, S1>(l.h2, l.h1, H1, g + flat_w_off(F, 1), first);
-        bias_grad<H2, S2>(l.h2, g + flat_b_off(F, 1), first);
-        __syncthreads();
-        input_grad<H2, H1, S2, S1>(l.h2, w + flat_w_off(F, 1), l.h1, sc, l.h1);
-        __syncthreads();
-        // ---- layer 0: dW0 = dz0^T x (256 x F), db0
-        weight_grad<H1, S1, SX>(l.h1, l.xs, F, g + flat_w_off(F, 0), first);
-        bias_grad<H1, S1>(l.h1, g + flat_b_off(F, 0), first);
-        __syncthreads();
-    }
-}
-
 // T5: gradients of (mu, rho) from the per-pair weight gradients + per-block squared norms ----------
 __global__ __launch_bounds__(256) void train_grad_kernel(const float* __restrict__ dW, const float* __restrict__ eps,
                                                         const float* __restrict__ sigma, int S, int NB, int64_t P,
@@ -539,11 +215,29 @@ __global__ __launch_bounds__(256) void train_grad_kernel(const float* __restrict
     double nsq = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         float a = 0.0f, b = 0.0f;
-        for (int s = 0; s < S; ++s) {  // fixed order: deterministic
-            float d = dW[((int64_t)m * S + s) * NB * P + i];
-            for (int nb = 1; nb < NB; ++nb) d += dW[(((int64_t)m * S + s) * NB + nb) * P + i];  // row-block partials
-            a += d;
-            b = fmaf(d, eps[((int64_t)m * S + s) * P + i], b);
+        if (NB == 1) {  // the reference's batch size: the loads of eight samples are issued together, then summed in sample order
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                float d[8], e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = s0 + u < S;
+                    d[u] = in ? dW[((int64_t)m * S + s0 + u) * P + i] : 0.0f;
+                    e[u] = in ? eps[((int64_t)m * S + s0 + u) * P + i] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + u < S) {
+                        a += d[u];
+                        b = fmaf(d[u], e[u], b);
+                    }
+            }
+        } else {
+            for (int s = 0; s < S; ++s) {  // fixed order: deterministic
+                float d = dW[((int64_t)m * S + s) * NB * P + i];
+                for (int nb = 1; nb < NB; ++nb) d += dW[(((int64_t)m * S + s) * NB + nb) * P + i];  // row-block partials
+                a += d;
+                b = fmaf(d, eps[((int64_t)m * S + s) * P + i], b);
+            }
         }
         b *= sigma[m * P + i];
         gmu[m * P + i] = a;
@@ -658,17 +352,20 @@ static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const 
 int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, float* act, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
-    auto kern = mask_mode == 1 ? train_forward_kernel<1> : mask_mode == 2 ? train_forward_kernel<2> : train_forward_kernel<0>;
+    const int row_blocks = train_row_blocks(rows);
+    const bool wide = (int64_t)M * S * row_blocks <= kWideMaxWorkgroups;
+    auto kern = wide ? (mask_mode == 1 ? nt512::train_forward_kernel<1> : mask_mode == 2 ? nt512::train_forward_kernel<2> : nt512::train_forward_kernel<0>)
+                     : (mask_mode == 1 ? nt256::train_forward_kernel<1> : mask_mode == 2 ? nt256::train_forward_kernel<2> : nt256::train_forward_kernel<0>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(M * S, train_row_blocks(rows)), dim3(NT), lds, s, xb, x_stride, rows, F, S, WT,
+    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(wide ? nt512::NT : nt256::NT), lds, s, xb, x_stride, rows, F, S, WT,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y, act);
     return check_launch("train_forward");
 }
 
 int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, int S, int64_t rows, float alpha, float beta, float* delta,
                       float* loss, double* loss_acc, hipStream_t s) {
-    hipLaunchKernelGGL(train_loss_kernel, dim3(M), dim3(NT), 0, s, Y, yb, y_stride, S, rows, alpha, beta, delta, loss, loss_acc);
+    hipLaunchKernelGGL(nt256::train_loss_kernel, dim3(M), dim3(nt256::NT), 0, s, Y, yb, y_stride, S, rows, alpha, beta, delta, loss, loss_acc);
     return check_launch("train_loss");
 }
 
@@ -676,12 +373,14 @@ int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
                           int row_blocks, float* dW, const float* act, const TrainLossFuse* fuse, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
-    auto kern = mask_mode == 1 ? train_backward_kernel<1> : mask_mode == 2 ? train_backward_kernel<2> : train_backward_kernel<0>;
+    const bool wide = (int64_t)M * S * row_blocks <= kWideMaxWorkgroups;
+    auto kern = wide ? (mask_mode == 1 ? nt512::train_backward_kernel<1> : mask_mode == 2 ? nt512::train_backward_kernel<2> : nt512::train_backward_kernel<0>)
+                     : (mask_mode == 1 ? nt256::train_backward_kernel<1> : mask_mode == 2 ? nt256::train_backward_kernel<2> : nt256::train_backward_kernel<0>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
     LossFuse lf{};
     if (fuse) lf = LossFuse{fuse->Y, fuse->yb, fuse->y_stride, fuse->alpha, fuse->beta, fuse->loss, fuse->loss_acc};
-    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), lds, s, xb, x_stride, rows, F, S, W, WT,
+    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(wide ? nt512::NT : nt256::NT), lds, s, xb, x_stride, rows, F, S, W, WT,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, act, lf);
     return check_launch("train_backward");
 }
@@ -708,7 +407,8 @@ int launch_train_apply(float* mu, float* rho, float* sigma, int M, int F, const 
     hp.max_norm = max_norm;
     hp.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
     hp.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(train_adamw_kernel, dim3(64, M), dim3(256), 0, s, mu, rho, sigma, gmu, grho, am, av, P, normsq_part, kGradBlocks,
+    const unsigned adam_blocks = (unsigned)((2 * P + 255) / 256);  // one element per thread: the loop's loads do not serialise
+    hipLaunchKernelGGL(train_adamw_kernel, dim3(adam_blocks, M), dim3(256), 0, s, mu, rho, sigma, gmu, grho, am, av, P, normsq_part, kGradBlocks,
                        active, hp, gnorm);
     return check_launch("train_apply");
 }
