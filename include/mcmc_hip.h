@@ -266,6 +266,13 @@ int mcmc_train_step(mcmc_ctx* ctx, const mcmc_train_buffers* buffers, const mcmc
                     const uint8_t* active, float lr, float beta1, int64_t step, double* loss_acc,
                     mcmc_stream_t stream);
 
+/* Early stopping of bayesian_ensemble.py:183-193 for all members after an epoch, on the device (so the
+ * training loop need not wait for the epoch's losses): a member whose active flag is set either improves
+ * best[m] (bad[m] = 0) or counts a bad epoch, and its flag is cleared once bad[m] >= patience.
+ * epoch_loss, best: fp64 [M]; bad: int64 [M]; active: uint8 [M] (the flags mcmc_train_step reads). */
+int mcmc_train_early_stop(mcmc_ctx* ctx, const double* epoch_loss, double* best, int64_t* bad,
+                          uint8_t* active, int n_members, int64_t patience, mcmc_stream_t stream);
+
 /* ---- next row: the Temporal Fusion Transformer leg ------------------------ */
 /* models/temporal_fusion.py.  Parameters are ONE flat fp32 vector in the reference module's
  * named_parameters() order (input_projection, feature_grn, temporal_grn, attention, final_grn,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16 = 0, 1
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class MCMCLibraryError(RuntimeError):
@@ -84,6 +84,7 @@ SIGNATURES = {
     "mcmc_train_step": (_i32, [_ctx_p, C.POINTER(TrainBuffers), C.POINTER(TrainHyper), _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32,
                                _ptr, _u64, _i32, _ptr, _ptr, _ptr, _u64, _ptr, _f32, _f32, _i64, _ptr, _stream]),
     "mcmc_train_act_floats": (_i64, [_i64]),
+    "mcmc_train_early_stop": (_i32, [_ctx_p, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _stream]),
     "mcmc_tft_param_count": (_i64, [_i32]),
     "mcmc_tft_transpose": (_i32, [_ctx_p, _ptr, _ptr, _i32, _stream]),
     "mcmc_tft_forward": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _stream]),

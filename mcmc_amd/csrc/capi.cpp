@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 9; }
+int mcmc_abi_version(void) { return 10; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -351,6 +351,14 @@ int mcmc_train_backward_blocks(mcmc_ctx* ctx, const float* xb, int64_t rows, int
 }
 
 int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }
+
+int mcmc_train_early_stop(mcmc_ctx* ctx, const double* epoch_loss, double* best, int64_t* bad, uint8_t* active, int n_members,
+                          int64_t patience, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n_members >= 1, "n_members must be >= 1");
+    MCMC_REQUIRE(epoch_loss && best && bad && active, "NULL pointer");
+    return launch_train_early_stop(epoch_loss, best, bad, active, n_members, patience, (hipStream_t)stream);
+}
 
 int64_t mcmc_train_act_floats(int64_t rows) { return rows < 1 ? 0 : train_act_floats(rows); }
 

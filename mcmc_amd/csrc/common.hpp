@@ -68,6 +68,7 @@ int launch_loss_backward(const mcmc_ctx* ctx, const float* p, const float* t, in
                          float* grad, hipStream_t s);
 
 int launch_train_sigma(const float* rho, float* sigma, int64_t n, hipStream_t s);
+int launch_train_early_stop(const double* epoch_loss, double* best, int64_t* bad, uint8_t* active, int M, int64_t patience, hipStream_t s);
 int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F, int noise_mode, const float* eps_in, uint64_t seed,
                         float* eps, float* W, float* WT, hipStream_t s);
 // x_stride / y_stride: floats between consecutive members' batches (rows * F / rows when dense)

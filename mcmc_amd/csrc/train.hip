@@ -318,6 +318,22 @@ __global__ __launch_bounds__(256) void exp_kernel(const float* __restrict__ rho,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) sigma[i] = expf(rho[i]);
 }
 
+// Early stopping of bayesian_ensemble.py:183-193 for all members after an epoch (one thread per member): a member
+// still active improves its best epoch loss or counts a bad epoch, and is frozen once it has `patience` of them.
+__global__ void early_stop_kernel(const double* __restrict__ epoch_loss, double* __restrict__ best, int64_t* __restrict__ bad,
+                                  uint8_t* __restrict__ active, int M, int64_t patience) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M || !active[m]) return;
+    const double el = epoch_loss[m];
+    if (el < best[m]) {
+        best[m] = el;
+        bad[m] = 0;
+    } else {
+        bad[m] += 1;
+    }
+    if (bad[m] >= patience) active[m] = 0;
+}
+
 constexpr int kGradBlocks = 128;
 
 }  // namespace
@@ -325,6 +341,11 @@ constexpr int kGradBlocks = 128;
 int launch_train_sigma(const float* rho, float* sigma, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, rho, sigma, n);
     return check_launch("train_sigma");
+}
+
+int launch_train_early_stop(const double* epoch_loss, double* best, int64_t* bad, uint8_t* active, int M, int64_t patience, hipStream_t s) {
+    hipLaunchKernelGGL(early_stop_kernel, dim3((M + 63) / 64), dim3(64), 0, s, epoch_loss, best, bad, active, M, patience);
+    return check_launch("train_early_stop");
 }
 
 int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F, int noise_mode, const float* eps_in, uint64_t seed,

@@ -76,21 +76,27 @@ class EnsembleTrainer:
         self.gnorm = torch.empty(self.M, **f32)
         self.loss = torch.empty(self.M, **f32)
         self.t = 0  # AdamW step count (shared: all members start together; frozen members never resume)
-        self._Y = self._delta = self._dpbuf = self._bufs = self._act = None
+        self._Y = self._delta = self._Ybuf = self._dbuf = self._dpbuf = self._bufs = self._act = None
+        self._rows = -1
         self._hyper = TrainHyper(p_drop, alpha, beta, beta2, adam_eps, weight_decay, max_norm)
         h = self.eng.ctx.handle
         _lib.check(self.eng.lib.mcmc_train_sigma(h, _p(self.rho), _p(self.sigma), self.rho.numel(), _stream()), "mcmc_train_sigma")
 
     def _work(self, rows: int):
-        if self._Y is None or self._Y.shape[1] != rows:
-            self._Y = torch.empty(self.M * self.S, rows, dtype=torch.float32, device=self.eng.device)
-            self._delta = torch.empty(self.M, rows, dtype=torch.float32, device=self.eng.device)
-            # saved activations for the backward kernel of small batches (the reference's 32 rows: 2.9 MB for 50 pairs)
-            need = self.M * self.S * int(self.eng.lib.mcmc_train_act_floats(rows)) if rows <= self.ACT_MAX_ROWS else 0
-            if need == 0:
-                self._act = None
-            elif self._act is None or self._act.numel() < need:
-                self._act = torch.empty(need, dtype=torch.float32, device=self.eng.device)
+        """Work buffers for a batch of ``rows`` rows: Y [M*S, rows], delta [M, rows] (views of buffers that only grow,
+        so the ragged last batch of an epoch re-allocates nothing) and the saved-activation scratch."""
+        pairs = self.M * self.S
+        if self._Ybuf is None or self._Ybuf.numel() < pairs * rows:
+            self._Ybuf = torch.empty(pairs * rows, dtype=torch.float32, device=self.eng.device)
+            self._dbuf = torch.empty(self.M * rows, dtype=torch.float32, device=self.eng.device)
+        if rows != self._rows:
+            self._rows = rows
+            self._Y = self._Ybuf[:pairs * rows].view(pairs, rows)
+            self._delta = self._dbuf[:self.M * rows].view(self.M, rows)
+        # saved activations for the backward kernel of small batches (the reference's 32 rows: 2.9 MB for 50 pairs)
+        need = pairs * int(self.eng.lib.mcmc_train_act_floats(rows)) if rows <= self.ACT_MAX_ROWS else 0
+        if need and (self._act is None or self._act.numel() < need):
+            self._act = torch.empty(need, dtype=torch.float32, device=self.eng.device)
         return self._Y, self._delta
 
     def _buffers(self) -> TrainBuffers:
@@ -202,6 +208,42 @@ class EnsembleTrainer:
             loss_acc += self.loss.double()
         return self.loss
 
+    def run_batches(self, Xe: torch.Tensor, ye: torch.Tensor, bounds: Sequence[Tuple[int, int]], lrs: Sequence[float],
+                    b1s: Sequence[float], seeds: Sequence[int], *, active: Optional[torch.Tensor] = None,
+                    loss_acc: Optional[torch.Tensor] = None) -> None:
+        """The batches [b0, b1) of an epoch, one ``mcmc_train_step`` call each, addressed in place in the epoch's
+        shuffled tensors Xe [M,N,F] / ye [M,N] (contiguous fp32 on the device): ``step(Xe[:, b0:b1], ye[:, b0:b1], ...)``
+        with Philox noise and Philox dropout for every batch, without the per-step tensor slicing and argument checks.
+        Batches of more than one row block fall back to ``step``."""
+        lib, h = self.eng.lib, self.eng.ctx.handle
+        M, S, F = self.M, self.S, self.F
+        if tuple(Xe.shape[::2]) != (M, F) or tuple(ye.shape) != (M, Xe.shape[1]):
+            raise ValueError(f"Xe must be [{M}, N, {F}] and ye [{M}, N], got {tuple(Xe.shape)} / {tuple(ye.shape)}")
+        if not (Xe.is_cuda and ye.is_cuda and Xe.is_contiguous() and ye.is_contiguous() and Xe.dtype == ye.dtype == torch.float32):
+            raise ValueError("Xe / ye must be contiguous fp32 tensors on the HIP device")
+        if not (len(bounds) == len(lrs) == len(b1s) == len(seeds)):
+            raise ValueError("bounds, lrs, b1s and seeds must have one entry per batch")
+        N = Xe.shape[1]
+        if any(not (0 <= b0 < b1 <= N) for b0, b1 in bounds):
+            raise ValueError(f"batch bounds outside [0, {N}]")
+        if loss_acc is not None and (loss_acc.dtype != torch.float64 or loss_acc.numel() != M or not loss_acc.is_cuda
+                                     or not loss_acc.is_contiguous()):
+            raise ValueError(f"loss_acc must be a contiguous fp64 [{M}] device tensor")
+        max_rows = max(b1 - b0 for b0, b1 in bounds)
+        if _dp_world(None) > 1 or int(lib.mcmc_train_row_blocks(max_rows)) != 1:
+            for (b0, b1), lr, b1m, sd in zip(bounds, lrs, b1s, seeds):
+                self.step(Xe[:, b0:b1], ye[:, b0:b1], lr, b1m, seed=sd, active=active, loss_acc=loss_acc)
+            return
+        self._work(max_rows)  # buffers sized for the largest batch serve every batch of the epoch
+        bufs, hyper, st = ctypes.byref(self._buffers()), ctypes.byref(self._hyper), _stream()
+        xp, yp, ap, lp = Xe.data_ptr(), ye.data_ptr(), _p(active), _p(loss_acc)
+        for (b0, b1), lr, b1m, sd in zip(bounds, lrs, b1s, seeds):
+            self.t += 1
+            sd &= _U64
+            _lib.check(lib.mcmc_train_step(h, bufs, hyper, xp + 4 * b0 * F, N * F, yp + 4 * b0, N, b1 - b0, F, M, S, NOISE_PHILOX, None, sd,
+                                           MASK_PHILOX, None, None, None, sd, ap, lr, b1m, self.t, lp, st), "mcmc_train_step")
+        self._work(bounds[-1][1] - bounds[-1][0])  # predictions() describes the last batch
+
     def _dp_loss(self, Y: torch.Tensor, yb: torch.Tensor, rows: int, delta: torch.Tensor, group, global_rows: Optional[int]):
         """peak_weighted_loss with global-batch statistics on the piece-3 kernels (mcmc_loss_*): per member
         p = mean over samples of this rank's rows; partial sums all-reduced between the passes (group False:
@@ -299,12 +341,14 @@ def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epo
     bad = torch.zeros(M, dtype=torch.int64)
     alive = torch.ones(M, dtype=torch.bool)
     trained = [0] * M
-    # device copy of the rule: the active flags of the next epoch's steps
+    # device copy of the rule (mcmc_train_early_stop): the active flags of the next epoch's steps
     d_best = torch.full((M,), float("inf"), dtype=torch.float64, device=dev)
     d_bad = torch.zeros(M, dtype=torch.int64, device=dev)
-    d_alive = torch.ones(M, dtype=torch.bool, device=dev)
-    d_zero = torch.zeros(M, dtype=torch.int64, device=dev)
     active = torch.ones(M, dtype=torch.uint8, device=dev)
+    epoch_losses = torch.zeros(epochs, M, dtype=torch.float64, device=dev)  # row e: the sum of epoch e's batch losses
+    Xe = torch.empty(M, N, X.shape[1], dtype=torch.float32, device=dev)      # the epoch's shuffled rows, per member
+    ye = torch.empty(M, N, dtype=torch.float32, device=dev)
+    lib, h = trainer.eng.lib, trainer.eng.ctx.handle
     depth = max(0, int(lookahead))
     slots = depth + 2  # an epoch's pinned slot is re-used only after that epoch has been settled
     perm_pin = torch.empty(slots, M, N, dtype=torch.int64).pin_memory()
@@ -344,19 +388,16 @@ def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epo
         slot = epoch % slots
         for m in range(M):  # per-member permutation, drawn on the host generator like DataLoader's sampler
             torch.randperm(N, generator=generator, out=perm_pin[slot, m])
-        perm = perm_pin[slot].to(dev, non_blocking=True)
-        Xe = X[perm]                      # [M, N, F]
-        ye = y[perm]                      # [M, N]
-        epoch_loss = torch.zeros(M, dtype=torch.float64, device=dev)
-        for (b0, b1) in bounds:
-            trainer.step(Xe[:, b0:b1], ye[:, b0:b1], lrs[it], b1s[it], seed=(seed + _GOLDEN * (it + 1)) & _U64, active=active,
-                         loss_acc=epoch_loss)
-            it += 1
-        improved = epoch_loss < d_best
-        d_best = torch.where(improved, epoch_loss, d_best)
-        d_bad = torch.where(improved, d_zero, d_bad + 1)
-        d_alive = d_alive & (d_bad < patience)
-        active = d_alive.to(torch.uint8)
+        perm = perm_pin[slot].to(dev, non_blocking=True).view(-1)
+        torch.index_select(X, 0, perm, out=Xe.view(M * N, -1))  # Xe = X[perm]: [M, N, F]
+        torch.index_select(y, 0, perm, out=ye.view(M * N))      # ye = y[perm]: [M, N]
+        epoch_loss = epoch_losses[epoch]
+        nb = len(bounds)
+        trainer.run_batches(Xe, ye, bounds, lrs[it:it + nb], b1s[it:it + nb], [seed + _GOLDEN * (k + 1) for k in range(it, it + nb)],
+                            active=active, loss_acc=epoch_loss)
+        it += nb
+        _lib.check(lib.mcmc_train_early_stop(h, _p(epoch_loss), _p(d_best), _p(d_bad), _p(active), M, int(patience), _stream()),
+                   "mcmc_train_early_stop")
         loss_pin[slot].copy_(epoch_loss, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
