@@ -239,6 +239,39 @@ def test_train_step_strided_batches_and_epoch_loss_equal_separate_calls():
     assert torch.equal(la, lb) and torch.equal(a.mu, b.mu)
 
 
+def test_early_stop_kernel_matches_reference_rule():
+    """mcmc_train_early_stop == the bookkeeping of bayesian_ensemble.py:183-193 applied member by member (ties and NaN
+    losses count as 'no improvement'; a stopped member is never touched again)."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import Engine, _p, _stream
+    eng = Engine(torch.device(DEV))
+    lib, h = eng.lib, eng.ctx.handle
+    M, epochs, patience = 37, 40, 3
+    g = torch.Generator().manual_seed(4)
+    losses = torch.rand(epochs, M, generator=g, dtype=torch.float64).mul(4).round().div(4)  # many ties
+    losses[5, 3] = float("nan")
+    losses[:, 7] = torch.arange(epochs, 0, -1, dtype=torch.float64)                        # always improving: never stops
+    best = torch.full((M,), float("inf"), dtype=torch.float64, device=DEV)
+    bad = torch.zeros(M, dtype=torch.int64, device=DEV)
+    active = torch.ones(M, dtype=torch.uint8, device=DEV)
+    w_best, w_bad, w_alive = [float("inf")] * M, [0] * M, [True] * M
+    dl = losses.to(DEV)
+    for e in range(epochs):
+        _lib.check(lib.mcmc_train_early_stop(h, _p(dl[e]), _p(best), _p(bad), _p(active), M, patience, _stream()), "early_stop")
+        for m in range(M):
+            if not w_alive[m]:
+                continue
+            if float(losses[e, m]) < w_best[m]:
+                w_best[m], w_bad[m] = float(losses[e, m]), 0
+            else:
+                w_bad[m] += 1
+            if w_bad[m] >= patience:
+                w_alive[m] = False
+        assert active.cpu().tolist() == [int(a) for a in w_alive], e
+        assert bad.cpu().tolist() == w_bad and best.cpu().tolist() == w_best, e
+    assert w_alive[7] and not all(w_alive)
+
+
 def test_train_capi_rejects_bad_arguments():
     from mcmc_amd import _lib
     from mcmc_amd.engine import Engine
