@@ -17,6 +17,7 @@ There is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import functools
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -294,24 +295,30 @@ class EnsembleTrainer:
                     off += nb
 
 
-def one_cycle_schedule(epochs: int, steps_per_epoch: int) -> Tuple[List[float], List[float]]:
-    """(lr, beta1) for every step of the reference's AdamW(lr=1e-3) + OneCycleLR(max_lr=0.01,
-    pct_start=0.3, cos) (bayesian_ensemble.py:137-150), produced by torch's scheduler itself on a
-    throw-away host parameter."""
+@functools.lru_cache(maxsize=16)
+def _one_cycle_schedule(epochs: int, steps_per_epoch: int) -> Tuple[Tuple[float, ...], Tuple[float, ...]]:
     dummy = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.AdamW([dummy], lr=0.001, weight_decay=0.01)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.01, epochs=epochs, steps_per_epoch=steps_per_epoch, pct_start=0.3,
                                                 anneal_strategy="cos")
+    opt.step()  # once, so the scheduler sees an optimiser that has stepped; the schedule depends on the step index alone
     lrs, b1s = [], []
     total = epochs * steps_per_epoch
+    g = opt.param_groups[0]
     for i in range(total):
-        g = opt.param_groups[0]
         lrs.append(float(g["lr"]))
         b1s.append(float(g["betas"][0]))
         if i + 1 < total:
-            opt.step()
             sched.step()
-    return lrs, b1s
+    return tuple(lrs), tuple(b1s)
+
+
+def one_cycle_schedule(epochs: int, steps_per_epoch: int) -> Tuple[List[float], List[float]]:
+    """(lr, beta1) for every step of the reference's AdamW(lr=1e-3) + OneCycleLR(max_lr=0.01,
+    pct_start=0.3, cos) (bayesian_ensemble.py:137-150), produced by torch's scheduler itself on a
+    throw-away host parameter (cached per (epochs, steps_per_epoch): main.py fits one ensemble per feature subset)."""
+    lrs, b1s = _one_cycle_schedule(int(epochs), int(steps_per_epoch))
+    return list(lrs), list(b1s)
 
 
 def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epochs: int = 400, batch_size: int = 32, *,

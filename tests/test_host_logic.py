@@ -323,3 +323,23 @@ def test_tft_module_parameters_follow_the_reference_layout():
         m.predict(torch.zeros(40, 11))
     with pytest.raises(ValueError):
         m.predict(torch.zeros(40, 5))
+
+
+def test_one_cycle_schedule_equals_torch_stepwise():
+    """train.one_cycle_schedule (scheduler stepped alone, cached) == the (lr, beta1) sequence a training loop sees when
+    it calls optimizer.step(); scheduler.step() after every batch (bayesian_ensemble.py:137-150,180-181), and the
+    oracle's closed form."""
+    from mcmc_amd.train import one_cycle_schedule
+    epochs, spe = 7, 12
+    lrs, b1s = one_cycle_schedule(epochs, spe)
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([dummy], lr=0.001, weight_decay=0.01)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.01, epochs=epochs, steps_per_epoch=spe, pct_start=0.3, anneal_strategy="cos")
+    for i in range(epochs * spe):
+        g = opt.param_groups[0]
+        assert float(g["lr"]) == lrs[i] and float(g["betas"][0]) == b1s[i], i
+        if i + 1 < epochs * spe:
+            opt.step()
+            sched.step()
+    assert one_cycle_schedule(epochs, spe) == (lrs, b1s)  # cached copy, fresh lists
+    assert lrs[0] == pytest.approx(0.01 / 25) and max(lrs) == pytest.approx(0.01, rel=1e-3) and b1s[0] == pytest.approx(0.95)
