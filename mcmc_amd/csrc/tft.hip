@@ -97,6 +97,21 @@ __device__ __forceinline__ void dense8(const float* in, int stride, int row0, co
     }
 }
 
+// s + sum_{k<N} vec[k] * Mat[k*ld + c], k ascending (`vec` in LDS, Mat in global memory): the loads of 16 k are
+// issued together - a plain loop waits one L2 round trip per k
+template <int N>
+__device__ __forceinline__ float dot_col(const float* vec, const float* __restrict__ Mat, int ld, int c, float s) {
+#pragma unroll 1
+    for (int k0 = 0; k0 < N; k0 += 16) {
+        float w[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k] = Mat[(k0 + k) * ld + c];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s = fmaf(vec[k0 + k], w[k], s);
+    }
+    return s;
+}
+
 // ---- LDS ------------------------------------------------------------------------------------------------
 struct GrnBuf {
     float *h1, *h2, *gt, *xh, *rstd;  // [rows][64] x4, [rows]
@@ -227,11 +242,15 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
         const float b = PT[tft_off_proj_b(F) + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
-        for (int k = 0; k < F; ++k) {
-            const float wk = PT[k * HD + o];
+        float wk[kMaxInputDim];  // all columns' weights first: one L2 round trip
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) acc[rr] = fmaf(l.x[(r0 + rr) * XS + k], wk, acc[rr]);
-        }
+        for (int k = 0; k < kMaxInputDim; ++k) wk[k] = k < F ? PT[k * HD + o] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < kMaxInputDim; ++k)
+            if (k < F) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) acc[rr] = fmaf(l.x[(r0 + rr) * XS + k], wk[k], acc[rr]);
+            }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) l.u[0][(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
     }
@@ -255,9 +274,7 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) l.V[(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
         if (wv == 0) {
-            float q = A[kAttInB + o];
-            const float* ul = l.u[2] + (T - 1) * HD;
-            for (int k = 0; k < HD; ++k) q = fmaf(ul[k], A[kAttInW + k * 3 * HD + o], q);
+            const float q = dot_col<HD>(l.u[2] + (T - 1) * HD, A + kAttInW, 3 * HD, o, A[kAttInB + o]);
             l.qs[o] = q * 0.25f;  // q * sqrt(1/head_dim), head_dim = 16
         }
     }
@@ -294,8 +311,7 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
     for (int i = t; i < 8 * HD; i += NT) {
         float v = 0.0f;
         if (i < HD) {
-            v = A[kAttOutB + i];
-            for (int c = 0; c < HD; ++c) v = fmaf(l.ctx[c], A[kAttOutW + c * HD + i], v);
+            v = dot_col<HD>(l.ctx, A + kAttOutW, HD, i, A[kAttOutB + i]);
         }
         l.a_out[i] = v;
     }
@@ -507,9 +523,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
         const float c = l.ctx[o];
         for (int oo = wv * 16; oo < wv * 16 + 16; ++oo) GA[kAttOutW + oo * HD + o] = l.vec0[oo] * c;
         if (wv == 0) {
-            float s = 0.0f;
-            for (int oo = 0; oo < HD; ++oo) s = fmaf(l.vec0[oo], A[kAttOutW + oo * HD + o], s);
-            l.vec1[o] = s;  // dctx
+            l.vec1[o] = dot_col<HD>(l.vec0, A + kAttOutW, HD, o, 0.0f);  // dctx
         }
     }
     __syncthreads();
@@ -555,8 +569,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     for (int rr = 0; rr < 8; ++rr) du3[rr] = 0.0f;
     dense8<HD>(l.dz, HD, r0, A + kAttInW + HD * HD, HD, o, du3);       // dK Wk
     if (wv == (T - 1) / 8) {                                          // + Wq^T dq on the last row
-        float s = 0.0f;
-        for (int oo = 0; oo < HD; ++oo) s = fmaf(l.vec0[oo], A[kAttInW + oo * HD + o], s);
+        const float s = dot_col<HD>(l.vec0, A + kAttInW, HD, o, 0.0f);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr)
             if (r0 + rr == T - 1) du3[rr] += s;
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
 }
 
 // ---- flat optimiser: grad = sum_b dP[b], clip_grad_norm_, AdamW ------------------------------------------------
-constexpr int kFlatBlocks = 64;
+constexpr int kFlatBlocks = 256;  // about one parameter per thread at 67,585 parameters; <= 256: one partial per thread in flat_adamw
 
 __global__ __launch_bounds__(256) void flat_grad_kernel(const float* __restrict__ dP, int B, int64_t n, float* __restrict__ grad,
                                                        double* __restrict__ normsq_part) {
@@ -600,7 +613,14 @@ __global__ __launch_bounds__(256) void flat_grad_kernel(const float* __restrict_
     double nsq = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float a = 0.0f;
-        for (int b = 0; b < B; ++b) a += dP[(int64_t)b * n + i];  // fixed order: deterministic
+        for (int b0 = 0; b0 < B; b0 += 8) {  // eight windows' loads in flight, summed in window order: deterministic
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = b0 + u < B ? dP[(int64_t)(b0 + u) * n + i] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b0 + u < B) a += d[u];
+        }
         grad[i] = a;
         nsq += (double)a * a;
     }
@@ -618,8 +638,15 @@ struct FlatHyper {
 __global__ __launch_bounds__(256) void flat_adamw_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ am,
                                                         float* __restrict__ av, int64_t n, const double* __restrict__ normsq_part,
                                                         int nparts, FlatHyper hp, float* __restrict__ gnorm) {
-    double nsq = 0.0;
-    for (int i = 0; i < nparts; ++i) nsq += normsq_part[i];
+    // squared norm from the per-block partials (nparts <= 256): one partial per thread, a fixed shuffle tree per wave,
+    // then the four wave sums in order - the same value in every workgroup and every run
+    __shared__ double wsum[4];
+    double v = (int)threadIdx.x < nparts ? normsq_part[threadIdx.x] : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double nsq = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     const float total = (float)sqrt(nsq);
     if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm) gnorm[0] = total;
     float coef = hp.max_norm / (total + 1e-6f);  // torch.nn.utils.clip_grad_norm_
@@ -704,7 +731,7 @@ int launch_flat_update(float* param, int64_t n, const float* dP, int B, float* g
     hp.max_norm = max_norm;
     hp.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
     hp.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(flat_adamw_kernel, dim3(64), dim3(256), 0, s, param, grad, am, av, n, normsq_part, kFlatBlocks, hp, gnorm);
+    hipLaunchKernelGGL(flat_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, am, av, n, normsq_part, kFlatBlocks, hp, gnorm);
     return check_launch("flat_update");
 }
 
