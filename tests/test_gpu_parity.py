@@ -167,6 +167,27 @@ def test_ragged_row_counts(golden, B):
         assert np.max(np.abs(res.samples.cpu().numpy() - allp.numpy())) <= tol * max(1.0, float(allp.abs().max()))
 
 
+def test_empty_input_gives_empty_outputs(golden):
+    """Zero rows: the reference's predict() runs its loops over an empty batch and returns empty (time,) tensors
+    (bayesian_ensemble.py:225-252); so does the HIP path, for every dtype, with and without the interval."""
+    from mcmc_amd import mc_predict
+    from mcmc_amd.bayesian_ensemble import GPUBayesianEnsemble
+    g = golden("predict_small.npz")
+    d = _dev()
+    mu, rho = torch.from_numpy(g["mu"]).to(d), torch.from_numpy(g["rho"]).to(d)
+    X = torch.empty(0, 11, device=d)
+    for dtype in ("fp32", "bf16"):
+        for q in ((), (0.025, 0.975)):
+            res = mc_predict(X, mu, rho, 4, dtype=dtype, seed=3, q_levels=q)
+            assert res.mean.shape == (0,) and res.std.shape == (0,) and res.n_samples == mu.shape[0] * 4
+            assert res.quantiles is None or res.quantiles.shape == (len(q), 0)
+    from mcmc_amd import BayesianNetwork
+    ens = GPUBayesianEnsemble(input_dim=11, n_models=2, device=d)
+    ens.models = [BayesianNetwork(11).to(d) for _ in range(2)]
+    mean, std = ens.predict(X, num_samples=3)
+    assert mean.shape == (0,) and std.shape == (0,) and mean.names == ("batch",)
+
+
 def test_single_sample_std_is_nan(golden):
     from mcmc_amd import mc_predict
     g = golden("predict_small.npz")
