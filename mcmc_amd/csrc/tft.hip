@@ -227,6 +227,25 @@ __device__ __forceinline__ void grn_forward(const float* u, const GrnBuf& gb, fl
     __syncthreads();
 }
 
+// Touch every 128-byte line of a parameter image once at kernel start (a handful of loads per thread, all in flight
+// at once): the AdamW step rewrote the image since the last launch, so the first reader in each XCD misses its L2,
+// and without this the layers would take those misses one dependent round trip after the other.
+// Returns a value the caller must keep alive (see `keep`).
+__device__ __forceinline__ float touch_params(const float* __restrict__ Pimg, int n) {
+    constexpr int kSweeps = (64 * kMaxInputDim + 64 + 3 * kGrnSize + kAttSize + 65 + NT * 32 - 1) / (NT * 32);  // largest image
+    float v[kSweeps];
+#pragma unroll
+    for (int k = 0; k < kSweeps; ++k) {
+        const int i = (k * NT + (int)threadIdx.x) * 32;
+        v[k] = i < n ? Pimg[i] : 0.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kSweeps; ++k) s += v[k];
+    return s;
+}
+__device__ __forceinline__ void keep(float v) { asm volatile("" ::"v"(v)); }
+
 // ---- whole forward of one window; returns the prediction in every thread -----------------------------
 template <bool TRAIN>
 __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* __restrict__ xw, int64_t rows_left, int F, const float* __restrict__ P,
@@ -480,7 +499,9 @@ __global__ __launch_bounds__(NT, 1) void tft_forward_kernel(const float* __restr
     w.T = T;
     int64_t s0 = start[blockIdx.x];
     if (s0 < 0 || s0 > n_rows) s0 = n_rows;  // an invalid start reads an all-zero window instead of faulting
+    const float warm = TRAIN ? touch_params(PT, tft_param_count(F)) : 0.0f;  // eval: repeated predicts find the image in L2
     const float y = tft_forward_window<TRAIN>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
+    keep(warm);
     if (threadIdx.x == 0) pred[blockIdx.x] = y;
 }
 
@@ -496,7 +517,9 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     const int t = threadIdx.x, o = t & 63, wv = t >> 6, r0 = wv * 8;
     int64_t s0 = start[blockIdx.x];
     if (s0 < 0 || s0 > n_rows) s0 = n_rows;
+    const float warm = touch_params(PT, tft_param_count(F)) + touch_params(P, tft_param_count(F));
     tft_forward_window<true>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
+    keep(warm);
     float* G = dP + (int64_t)blockIdx.x * tft_param_count(F);
     const float sc = ms.mode != 0 ? ms.scale : 1.0f;
     const float dy = delta[blockIdx.x];
