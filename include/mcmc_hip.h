@@ -299,6 +299,23 @@ int mcmc_tft_backward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32
                       const uint8_t* mask_feature, const uint8_t* mask_temporal,
                       const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
                       float p_drop, const float* delta, float* dP, mcmc_stream_t stream);
+/* The same pair with autograd's saved tensors instead of the recompute (:249-252: forward, then
+ * loss.backward() on what the forward kept): mcmc_tft_forward_save also leaves every window's
+ * activations in act [n_windows * mcmc_tft_act_floats()] (124 KB per window), and
+ * mcmc_tft_backward_saved reloads them.  Same numbers, bit for bit, as mcmc_tft_forward /
+ * mcmc_tft_backward with the same masks. */
+int64_t mcmc_tft_act_floats(void);
+int mcmc_tft_forward_save(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows,
+                          int seq_len, int num_features, const float* P, const float* PT, int mask_mode,
+                          const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                          const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
+                          float p_drop, float* pred, float* act, mcmc_stream_t stream);
+int mcmc_tft_backward_saved(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows,
+                            int seq_len, int num_features, const float* P, const float* PT, int mask_mode,
+                            const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                            const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
+                            float p_drop, const float* delta, float* dP, const float* act,
+                            mcmc_stream_t stream);
 /* grad = sum over the n_partials rows of dP; clip_grad_norm_(max_norm) (:254); torch's AdamW step
  * (:255) on a flat parameter vector.  norm_scratch: fp64 [mcmc_flat_norm_blocks()]. */
 int mcmc_flat_norm_blocks(void);

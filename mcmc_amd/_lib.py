@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16 = 0, 1
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class MCMCLibraryError(RuntimeError):
@@ -88,6 +88,11 @@ SIGNATURES = {
     "mcmc_tft_param_count": (_i64, [_i32]),
     "mcmc_tft_transpose": (_i32, [_ctx_p, _ptr, _ptr, _i32, _stream]),
     "mcmc_tft_forward": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _stream]),
+    "mcmc_tft_act_floats": (_i64, []),
+    "mcmc_tft_forward_save": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr,
+                                     _stream]),
+    "mcmc_tft_backward_saved": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr,
+                                       _ptr, _stream]),
     "mcmc_tft_backward": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr,
                                  _stream]),
     "mcmc_flat_norm_blocks": (_i32, []),

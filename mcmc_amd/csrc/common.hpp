@@ -102,13 +102,14 @@ int64_t train_act_floats(int64_t rows);  // act: [pairs][tiles] saved activation
 
 int tft_params(int F);
 int tft_flat_blocks();
+int64_t tft_act_floats();  // floats per window of the saved-activation buffer (act: forward writes, backward reads; nullptr: recompute)
 int launch_tft_transpose(const float* P, float* PT, int F, hipStream_t s);
 int launch_tft_forward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                        const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop, float* pred,
-                       hipStream_t s);
+                       float* act, hipStream_t s);
 int launch_tft_backward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                         const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop,
-                        const float* delta, float* dP, hipStream_t s);
+                        const float* delta, float* dP, const float* act, hipStream_t s);
 int launch_flat_update(float* param, int64_t n, const float* dP, int B, float* grad, float* am, float* av, double* normsq_part, float lr,
                        float beta1, float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm,
                        hipStream_t s);

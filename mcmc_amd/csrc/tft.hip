@@ -133,6 +133,13 @@ struct Lds {
 constexpr int kLdsFloats = TMAX * XS + 3 * TMAX * HD + 2 * (4 * TMAX * HD + TMAX) + (4 * 8 * HD + 8) + 2 * TMAX * HD + (HD + 2 * NH * TMAX + HD) +
                            2 * 8 * HD + 3 * TMAX * HD + 4 * HD + 2 * HD + NH * TMAX;
 
+// Everything the forward pass leaves in LDS (x ... out3) is one contiguous block at the start of the allocation: the
+// train-mode forward kernel can save it (124 KB per window) and the backward kernel reload it instead of
+// recomputing the window's forward pass (autograd's saved tensors).
+constexpr int kFwdFloats = TMAX * XS + 3 * TMAX * HD + 2 * (4 * TMAX * HD + TMAX) + (4 * 8 * HD + 8) + 2 * TMAX * HD + (HD + 2 * NH * TMAX + HD) +
+                           2 * 8 * HD;
+static_assert(kFwdFloats % 4 == 0, "saved activations are copied as float4");
+
 __device__ __forceinline__ Lds carve(float* p) {
     Lds l;
     auto take = [&](int n) { float* q = p; p += n; return q; };
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256) void tft_transpose_kernel(const float* __restr
 template <bool TRAIN>
 __global__ __launch_bounds__(NT, 1) void tft_forward_kernel(const float* __restrict__ X, int64_t n_rows, const int* __restrict__ start, int T, int F,
                                                             const float* __restrict__ P, const float* __restrict__ PT, TftMasks ms,
-                                                            float* __restrict__ pred) {
+                                                            float* __restrict__ pred, float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     Win w;
@@ -503,11 +510,18 @@ __global__ __launch_bounds__(NT, 1) void tft_forward_kernel(const float* __restr
     const float y = tft_forward_window<TRAIN>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
     keep(warm);
     if (threadIdx.x == 0) pred[blockIdx.x] = y;
+    if (act) {  // keep the window's activations for the backward kernel
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(act + (int64_t)blockIdx.x * kFwdFloats);
+        const float4* src = reinterpret_cast<const float4*>(smem);
+        for (int i = threadIdx.x; i < kFwdFloats / 4; i += NT) dst[i] = src[i];
+    }
 }
 
 __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __restrict__ X, int64_t n_rows, const int* __restrict__ start, int T, int F,
                                                              const float* __restrict__ P, const float* __restrict__ PT, TftMasks ms,
-                                                             const float* __restrict__ delta, float* __restrict__ dP) {
+                                                             const float* __restrict__ delta, float* __restrict__ dP,
+                                                             const float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     Win w;
@@ -517,8 +531,15 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     const int t = threadIdx.x, o = t & 63, wv = t >> 6, r0 = wv * 8;
     int64_t s0 = start[blockIdx.x];
     if (s0 < 0 || s0 > n_rows) s0 = n_rows;
-    const float warm = touch_params(PT, tft_param_count(F)) + touch_params(P, tft_param_count(F));
-    tft_forward_window<true>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
+    const float warm = (act ? 0.0f : touch_params(PT, tft_param_count(F))) + touch_params(P, tft_param_count(F));
+    if (act) {  // the forward kernel saved this window's activations: reload them
+        const float4* src = reinterpret_cast<const float4*>(act + (int64_t)blockIdx.x * kFwdFloats);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = t; i < kFwdFloats / 4; i += NT) dst[i] = src[i];
+        __syncthreads();
+    } else {
+        tft_forward_window<true>(l, X + s0 * F, n_rows - s0, F, P, PT, ms, w);
+    }
     keep(warm);
     float* G = dP + (int64_t)blockIdx.x * tft_param_count(F);
     const float sc = ms.mode != 0 ? ms.scale : 1.0f;
@@ -711,6 +732,7 @@ int set_lds(K kernel, const char* what) {
 
 int tft_params(int F) { return tft_param_count(F); }
 int tft_flat_blocks() { return kFlatBlocks; }
+int64_t tft_act_floats() { return kFwdFloats; }
 
 int launch_tft_transpose(const float* P, float* PT, int F, hipStream_t s) {
     hipLaunchKernelGGL(tft_transpose_kernel, dim3(64), dim3(256), 0, s, P, PT, F);
@@ -719,25 +741,25 @@ int launch_tft_transpose(const float* P, float* PT, int F, hipStream_t s) {
 
 int launch_tft_forward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                        const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop, float* pred,
-                       hipStream_t s) {
+                       float* act, hipStream_t s) {
     const size_t lds = kLdsFloats * sizeof(float);
     const TftMasks ms = make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop);
     if (mask_mode == 0) {
         if (int rc = set_lds(tft_forward_kernel<false>, "tft_forward")) return rc;
-        hipLaunchKernelGGL(tft_forward_kernel<false>, dim3(B), dim3(NT), lds, s, X, n_rows, start, T, F, P, PT, ms, pred);
+        hipLaunchKernelGGL(tft_forward_kernel<false>, dim3(B), dim3(NT), lds, s, X, n_rows, start, T, F, P, PT, ms, pred, act);
     } else {
         if (int rc = set_lds(tft_forward_kernel<true>, "tft_forward")) return rc;
-        hipLaunchKernelGGL(tft_forward_kernel<true>, dim3(B), dim3(NT), lds, s, X, n_rows, start, T, F, P, PT, ms, pred);
+        hipLaunchKernelGGL(tft_forward_kernel<true>, dim3(B), dim3(NT), lds, s, X, n_rows, start, T, F, P, PT, ms, pred, act);
     }
     return check_launch("tft_forward");
 }
 
 int launch_tft_backward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                         const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop,
-                        const float* delta, float* dP, hipStream_t s) {
+                        const float* delta, float* dP, const float* act, hipStream_t s) {
     if (int rc = set_lds(tft_backward_kernel, "tft_backward")) return rc;
     hipLaunchKernelGGL(tft_backward_kernel, dim3(B), dim3(NT), kLdsFloats * sizeof(float), s, X, n_rows, start, T, F, P, PT,
-                       make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop), delta, dP);
+                       make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop), delta, dP, act);
     return check_launch("tft_backward");
 }
 

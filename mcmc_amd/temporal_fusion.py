@@ -105,6 +105,8 @@ class TFTEngine:
         self.dP = torch.empty(max_windows, self.n, **f32)
         self.pred = torch.empty(max_windows, **f32)
         self.delta = torch.empty(max_windows, **f32)
+        # the train-mode forward leaves every window's activations here for the backward kernel (124 KB per window)
+        self.act = torch.empty(max_windows * int(self.lib.mcmc_tft_act_floats()), **f32)
         self.p_drop, self.weight_decay, self.beta2, self.adam_eps, self.max_norm = p_drop, weight_decay, beta2, adam_eps, max_norm
         self.t = 0
         self._pt_stale = True
@@ -157,14 +159,18 @@ class TFTEngine:
             raise ValueError(f"batch of {B} windows exceeds max_windows = {self.max_windows}")
         yb = yb.to(device=self.eng.device, dtype=torch.float32).contiguous()
         X = X.contiguous()
-        pred = self.forward(X, start, masks=masks, seed=None if masks is not None else seed, out=self.pred)
+        B = self._B = start.numel()
+        self._transpose()
         st = _stream()
+        mode, m = self._mask_args(masks, None if masks is not None else seed)
+        pred = self.pred
+        _lib.check(self.lib.mcmc_tft_forward_save(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
+                                                  seed & _U64, self.p_drop, _p(pred), _p(self.act), st), "mcmc_tft_forward_save")
         _lib.check(self.lib.mcmc_train_loss(self.h, _p(pred), _p(yb), 1, 1, B, alpha, beta, _p(self.delta), _p(self.loss), st),
                    "mcmc_train_loss")
-        self._B = B
-        mode, m = self._mask_args(masks, None if masks is not None else seed)
-        _lib.check(self.lib.mcmc_tft_backward(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
-                                              seed & _U64, self.p_drop, _p(self.delta), _p(self.dP), st), "mcmc_tft_backward")
+        _lib.check(self.lib.mcmc_tft_backward_saved(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
+                                                    seed & _U64, self.p_drop, _p(self.delta), _p(self.dP), _p(self.act), st),
+                   "mcmc_tft_backward_saved")
         if update:
             self.t += 1
             _lib.check(self.lib.mcmc_flat_adamw(self.h, _p(self.P), self.n, _p(self.dP), B, _p(self.grad), _p(self.adam_m),

@@ -115,6 +115,36 @@ def test_tft_philox_dropout_matches_oracle_masks(golden):
     assert np.abs(evalp - got).max() > 1e-3      # dropout really was live
 
 
+def test_tft_saved_activations_equal_recompute(golden):
+    """step() (train-mode forward that saves the windows' activations + backward that reloads them) == the plain
+    forward / backward pair whose backward recomputes the forward pass: predictions, loss and every window's
+    parameter gradient, bit for bit, with Philox dropout live and with a ragged batch after a full one."""
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import _p, _stream
+    z = golden("tft_fwd.npz")
+    F = z["X"].shape[1]
+    X = torch.from_numpy(z["X"]).to(DEV)
+    te = _engine(z["flat"], F)
+    lib, h = te.lib, te.h
+    g = torch.Generator().manual_seed(2)
+    for n_win, seed in ((32, 77), (13, 78)):
+        start = torch.randperm(336, generator=g)[:n_win].to(dtype=torch.int32, device=DEV)
+        yb = torch.randn(n_win, generator=g).to(DEV)
+        loss = te.step(X, start, yb, 1e-3, 0.9, seed=seed, update=False).clone()
+        pred = torch.empty(n_win, device=DEV)
+        delta = torch.empty(n_win, device=DEV)
+        l2 = torch.empty(1, device=DEV)
+        dP = torch.full((n_win, te.n), float("nan"), device=DEV)
+        none = [_p(None)] * 4
+        st = _stream()
+        _lib.check(lib.mcmc_tft_forward(h, _p(X), X.shape[0], _p(start), n_win, 30, F, _p(te.P), _p(te.PT), 2, *none, seed, 0.1, _p(pred), st), "f")
+        _lib.check(lib.mcmc_train_loss(h, _p(pred), _p(yb), 1, 1, n_win, 2.0, 0.5, _p(delta), _p(l2), st), "l")
+        _lib.check(lib.mcmc_tft_backward(h, _p(X), X.shape[0], _p(start), n_win, 30, F, _p(te.P), _p(te.PT), 2, *none, seed, 0.1, _p(delta),
+                                         _p(dP), st), "b")
+        assert torch.equal(te.pred[:n_win], pred) and torch.equal(loss, l2)
+        assert torch.equal(te.dP[:n_win], dP)
+
+
 def test_tft_model_trains_and_predicts_end_to_end(golden):
     from mcmc_amd.temporal_fusion import TFTModel
     z = golden("predict_cfg1.npz")
