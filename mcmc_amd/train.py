@@ -356,7 +356,7 @@ def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epo
     Xe = torch.empty(M, N, X.shape[1], dtype=torch.float32, device=dev)      # the epoch's shuffled rows, per member
     ye = torch.empty(M, N, dtype=torch.float32, device=dev)
     lib, h = trainer.eng.lib, trainer.eng.ctx.handle
-    depth = max(0, int(lookahead))
+    depth = max(0, min(int(lookahead), (1 << 24) // max(1, M * N)))  # the pinned permutation ring stays below ~1.3 GB for huge N
     slots = depth + 2  # an epoch's pinned slot is re-used only after that epoch has been settled
     perm_pin = torch.empty(slots, M, N, dtype=torch.int64).pin_memory()
     loss_pin = torch.empty(slots, M, dtype=torch.float64).pin_memory()
