@@ -231,7 +231,7 @@ class EnsembleTrainer:
                                      or not loss_acc.is_contiguous()):
             raise ValueError(f"loss_acc must be a contiguous fp64 [{M}] device tensor")
         max_rows = max(b1 - b0 for b0, b1 in bounds)
-        if _dp_world(None) > 1 or int(lib.mcmc_train_row_blocks(max_rows)) != 1:
+        if int(lib.mcmc_train_row_blocks(max_rows)) != 1:
             for (b0, b1), lr, b1m, sd in zip(bounds, lrs, b1s, seeds):
                 self.step(Xe[:, b0:b1], ye[:, b0:b1], lr, b1m, seed=sd, active=active, loss_acc=loss_acc)
             return
