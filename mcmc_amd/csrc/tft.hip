@@ -112,6 +112,39 @@ __device__ __forceinline__ float dot_col(const float* vec, const float* __restri
     return s;
 }
 
+// The same product as dense8<64> for ALL 32 rows of a tile on the matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32
+// FMAs): acc[rr] += sum_{j<64} in[(8*wave+rr)*64 + j] * Mat[j*ld + lane].  Every wave of the workgroup takes part:
+// wave = (mo, kh) computes output features 32*mo.. for k = 32*kh..32*kh+31 (16 MFMAs, its 16 weight loads in flight
+// together, activations as four 16-byte LDS reads per lane: lane (row, h) feeds k = 8j + 4h + i at step (j, i)); the
+// two k-halves meet in `stage` [2][32][65] (LDS) and come back in dense8's layout - rows 8*wave.., lane = feature.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kStageFloats = 2 * TMAX * 65;
+__device__ __forceinline__ void dense32_mfma(const float* in, const float* __restrict__ Mat, int ld, float* stage, float (&acc)[8]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane & 31, h = lane >> 5, mo = wv & 1, kh = wv >> 1;
+    float av[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[4 * j + i] = Mat[(32 * kh + 8 * j + 4 * h + i) * ld + 32 * mo + r];
+    f32x16 d = {0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(in + r * HD + 32 * kh + 8 * j + 4 * h);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * j + 0], q.x, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * j + 1], q.y, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * j + 2], q.z, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * j + 3], q.w, d, 0, 0, 0);
+    }
+    float* st = stage + kh * (TMAX * 65) + r * 65 + 32 * mo;  // register i of lane (r, h) holds D[feature acc_feature(i, h)][row r]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[acc_feature(i, h)] = d[i];
+    __syncthreads();
+    const float* s0 = stage + (wv * 8) * 65 + lane;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) acc[rr] += s0[rr * 65] + s0[TMAX * 65 + rr * 65];
+    __syncthreads();
+}
+
 // ---- LDS ------------------------------------------------------------------------------------------------
 struct GrnBuf {
     float *h1, *h2, *gt, *xh, *rstd;  // [rows][64] x4, [rows]
@@ -161,6 +194,7 @@ __device__ __forceinline__ Lds carve(float* p) {
     l.ctx = take(HD);
     l.a_out = take(8 * HD);
     l.out3 = take(8 * HD);
+    static_assert(kStageFloats <= 3 * TMAX * HD, "the forward pass's MFMA staging tile aliases dU | dz | dzT");
     l.dU = take(TMAX * HD);
     l.dz = take(TMAX * HD);
     l.dzT = take(HD * TMAX);
@@ -174,9 +208,11 @@ __device__ __forceinline__ Lds carve(float* p) {
 // ---- GRN forward on a row tile: wave `wv` owns rows 8wv..8wv+7 when wv < n_waves --------------------
 // u -> out (both [rows][64] in LDS); stores h1 (post dropout), h2, gate, xhat, rstd for the backward pass.
 // `row_of(r)` gives the window row of tile row r (masks); `live(r)` whether the row exists.
-template <bool TRAIN>
+// WIDE (all four waves active, 32-row tiles): the four dense layers run on the matrix pipe (dense32_mfma, `stage` =
+// kStageFloats of LDS scratch); otherwise (the final GRN's single live row) on the VALU.
+template <bool TRAIN, bool WIDE>
 __device__ __forceinline__ void grn_forward(const float* u, const GrnBuf& gb, float* out, const float* __restrict__ PT, int n_waves,
-                                            const TftMasks& ms, const Win& w, int which, int row_shift, int n_live) {
+                                            const TftMasks& ms, const Win& w, int which, int row_shift, int n_live, float* stage) {
     const int o = threadIdx.x & 63, wv = threadIdx.x >> 6, r0 = wv * 8;
     const bool act = wv < n_waves;
     float acc[8];
@@ -184,7 +220,10 @@ __device__ __forceinline__ void grn_forward(const float* u, const GrnBuf& gb, fl
         const float b = PT[kGrnB1 + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
-        dense8<HD>(u, HD, r0, PT + kGrnW1, HD, o, acc);
+        if (!WIDE) dense8<HD>(u, HD, r0, PT + kGrnW1, HD, o, acc);
+    }
+    if (WIDE) dense32_mfma(u, PT + kGrnW1, HD, stage, acc);
+    if (act) {
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int r = r0 + rr;
@@ -199,7 +238,10 @@ __device__ __forceinline__ void grn_forward(const float* u, const GrnBuf& gb, fl
         const float b = PT[kGrnB2 + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
-        dense8<HD>(gb.h1, HD, r0, PT + kGrnW2, HD, o, acc);
+        if (!WIDE) dense8<HD>(gb.h1, HD, r0, PT + kGrnW2, HD, o, acc);
+    }
+    if (WIDE) dense32_mfma(gb.h1, PT + kGrnW2, HD, stage, acc);
+    if (act) {
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             h2v[rr] = r0 + rr < n_live ? elu(acc[rr]) : 0.0f;
@@ -211,8 +253,16 @@ __device__ __forceinline__ void grn_forward(const float* u, const GrnBuf& gb, fl
         const float b = PT[kGrnBg + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
-        dense8<HD>(u, HD, r0, PT + kGrnWg, HD, o, acc);               // gate input = [u | h2]  (transposed gate: [128][64])
-        dense8<HD>(gb.h2, HD, r0, PT + kGrnWg + HD * HD, HD, o, acc);
+        if (!WIDE) {
+            dense8<HD>(u, HD, r0, PT + kGrnWg, HD, o, acc);               // gate input = [u | h2]  (transposed gate: [128][64])
+            dense8<HD>(gb.h2, HD, r0, PT + kGrnWg + HD * HD, HD, o, acc);
+        }
+    }
+    if (WIDE) {
+        dense32_mfma(u, PT + kGrnWg, HD, stage, acc);
+        dense32_mfma(gb.h2, PT + kGrnWg + HD * HD, HD, stage, acc);
+    }
+    if (act) {
         const float gamma = PT[kGrnGamma + o], beta = PT[kGrnBeta + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
@@ -281,8 +331,8 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
         for (int rr = 0; rr < 8; ++rr) l.u[0][(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
     }
     __syncthreads();
-    grn_forward<TRAIN>(l.u[0], l.g[0], l.u[1], PT + tft_off_grn(F, 0), 4, ms, w, 0, 0, T);
-    grn_forward<TRAIN>(l.u[1], l.g[1], l.u[2], PT + tft_off_grn(F, 1), 4, ms, w, 1, 0, T);
+    grn_forward<TRAIN, true>(l.u[0], l.g[0], l.u[1], PT + tft_off_grn(F, 0), 4, ms, w, 0, 0, T, l.dU);
+    grn_forward<TRAIN, true>(l.u[1], l.g[1], l.u[2], PT + tft_off_grn(F, 1), 4, ms, w, 1, 0, T, l.dU);
     // ---- attention (:139-144), query = last row only
     const float* A = PT + tft_off_att(F);  // transposed in_proj: [64][192]; out_proj [64][64]
     {
@@ -290,13 +340,13 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
         float b = A[kAttInB + HD + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
-        dense8<HD>(l.u[2], HD, r0, A + kAttInW + HD, 3 * HD, o, acc);
+        dense32_mfma(l.u[2], A + kAttInW + HD, 3 * HD, l.dU, acc);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) l.K[(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
         b = A[kAttInB + 2 * HD + o];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) acc[rr] = b;
-        dense8<HD>(l.u[2], HD, r0, A + kAttInW + 2 * HD, 3 * HD, o, acc);
+        dense32_mfma(l.u[2], A + kAttInW + 2 * HD, 3 * HD, l.dU, acc);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) l.V[(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
         if (wv == 0) {
@@ -343,7 +393,7 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
     }
     __syncthreads();
     // final GRN on the last row (tile row 0 <-> window row T-1)
-    grn_forward<TRAIN>(l.a_out, l.g[2], l.out3, PT + tft_off_grn(F, 2), 1, ms, w, 2, T - 1, 1);
+    grn_forward<TRAIN, false>(l.a_out, l.g[2], l.out3, PT + tft_off_grn(F, 2), 1, ms, w, 2, T - 1, 1, nullptr);
     const float* Wo = P + tft_off_out(F);
     float y = wave_sum(l.out3[o] * Wo[o]) + Wo[HD];
     return y;
