@@ -186,6 +186,7 @@ __device__ __forceinline__ Lds carve(float* p) {
         l.g[i].xh = take(rows * HD);
         l.g[i].rstd = take(rows);
     }
+    static_assert(kStageFloats <= 2 * TMAX * HD + HD, "the backward pass's MFMA staging tile aliases K | V | qs");
     l.K = take(TMAX * HD);
     l.V = take(TMAX * HD);
     l.qs = take(HD);
@@ -479,9 +480,19 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     wgrad<R>(l.dzT, u, HD, HD, G + kGrnWg, 2 * HD, 0);
     wgrad<R>(l.dzT, gb.h2, HD, HD, G + kGrnWg, 2 * HD, HD);
     bgrad<R>(l.dzT, G + kGrnBg);
+    // input gradients: 32-row tiles on the matrix pipe (staging tile = K | V | qs, dead once the attention backward is
+    // done), the final GRN's single row on the VALU
+    constexpr bool WIDE = R == TMAX;
+    float* stage = l.K;
+    if (WIDE) {
+        dense32_mfma(l.dz, Pg + kGrnWg, 2 * HD, stage, du);
+        dense32_mfma(l.dz, Pg + kGrnWg + HD, 2 * HD, stage, dh2);
+    }
     if (act) {
-        dense8<HD>(l.dz, HD, r0, Pg + kGrnWg, 2 * HD, o, du);
-        dense8<HD>(l.dz, HD, r0, Pg + kGrnWg + HD, 2 * HD, o, dh2);
+        if (!WIDE) {
+            dense8<HD>(l.dz, HD, r0, Pg + kGrnWg, 2 * HD, o, du);
+            dense8<HD>(l.dz, HD, r0, Pg + kGrnWg + HD, 2 * HD, o, dh2);
+        }
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const float h2v = gb.h2[(r0 + rr) * HD + o];
@@ -494,10 +505,11 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     __syncthreads();
     wgrad<R>(l.dzT, gb.h1, HD, HD, G + kGrnW2, HD, 0);
     bgrad<R>(l.dzT, G + kGrnB2);
-    if (act) {
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) tmp[rr] = 0.0f;
-        dense8<HD>(l.dz, HD, r0, Pg + kGrnW2, HD, o, tmp);
+    for (int rr = 0; rr < 8; ++rr) tmp[rr] = 0.0f;
+    if (WIDE) dense32_mfma(l.dz, Pg + kGrnW2, HD, stage, tmp);
+    if (act) {
+        if (!WIDE) dense8<HD>(l.dz, HD, r0, Pg + kGrnW2, HD, o, tmp);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) tmp[rr] *= dfactor(gb.h1[(r0 + rr) * HD + o], scale);  // d a1
     }
@@ -506,8 +518,9 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     __syncthreads();
     wgrad<R>(l.dzT, u, HD, HD, G + kGrnW1, HD, 0);
     bgrad<R>(l.dzT, G + kGrnB1);
+    if (WIDE) dense32_mfma(l.dz, Pg + kGrnW1, HD, stage, du);
     if (act) {
-        dense8<HD>(l.dz, HD, r0, Pg + kGrnW1, HD, o, du);
+        if (!WIDE) dense8<HD>(l.dz, HD, r0, Pg + kGrnW1, HD, o, du);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) l.dU[(r0 + rr) * HD + o] = du[rr];
     }
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     float du3[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) du3[rr] = 0.0f;
-    dense8<HD>(l.dz, HD, r0, A + kAttInW + HD * HD, HD, o, du3);       // dK Wk
+    dense32_mfma(l.dz, A + kAttInW + HD * HD, HD, l.K, du3);           // dK Wk (K, V, qs are dead: staging tile)
     if (wv == (T - 1) / 8) {                                          // + Wq^T dq on the last row
         const float s = dot_col<HD>(l.vec0, A + kAttInW, HD, o, 0.0f);
 #pragma unroll
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     __syncthreads();
     wgrad<TMAX>(l.dzT, l.u[2], HD, HD, GA + kAttInW + 2 * HD * HD, HD, 0);  // value rows
     bgrad<TMAX>(l.dzT, GA + kAttInB + 2 * HD);
-    dense8<HD>(l.dz, HD, r0, A + kAttInW + 2 * HD * HD, HD, o, du3);       // + dV Wv
+    dense32_mfma(l.dz, A + kAttInW + 2 * HD * HD, HD, l.K, du3);           // + dV Wv
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) l.dU[(r0 + rr) * HD + o] = du3[rr];
     __syncthreads();
