@@ -423,6 +423,25 @@ __device__ __forceinline__ void wgrad(const float* dzT, const float* act, int st
         g[o * ld + col0 + k] = s;
     }
 }
+// The same weight gradient for a full tile (R = 32 rows, 64 x 64 weights, activation stride 64) on the matrix pipe:
+// D[o][k] = sum_r dzT[o][r] * act[r][k]; wave = (mo, nk) owns the 32 x 32 block of outputs 32*mo.. and inputs 32*nk..;
+// lane (m, h) feeds dzT[o = 32*mo + m][r] and act[r][k = 32*nk + m] for r = 8j + 4h + i at step (j, i).
+__device__ __forceinline__ void wgrad32_mfma(const float* dzT, const float* act, float* __restrict__ g, int ld, int col0) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 31, h = lane >> 5, mo = wv & 1, nk = wv >> 1;
+    f32x16 d = {0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(dzT + (32 * mo + m) * TMAX + 8 * j + 4 * h);
+        const float* b = act + (8 * j + 4 * h) * HD + 32 * nk + m;
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, b[0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, b[HD], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, b[2 * HD], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, b[3 * HD], d, 0, 0, 0);
+    }
+    float* out = g + (32 * mo) * ld + col0 + 32 * nk + m;  // register i of lane (m, h): D[o = acc_feature(i, h)][k = m]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[acc_feature(i, h) * ld] = d[i];
+}
 // bias gradient: g[o] = sum_r dzT[o][r]
 template <int R>
 __device__ __forceinline__ void bgrad(const float* dzT, float* __restrict__ g) {
@@ -477,8 +496,8 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     __syncthreads();
     l.red[wv * HD + o] = act ? dbet : 0.0f;
     // gate: dWg = dgp^T [u | h2], dbg; d[u | h2] += dgp Wg
-    wgrad<R>(l.dzT, u, HD, HD, G + kGrnWg, 2 * HD, 0);
-    wgrad<R>(l.dzT, gb.h2, HD, HD, G + kGrnWg, 2 * HD, HD);
+    if (R == TMAX) wgrad32_mfma(l.dzT, u, G + kGrnWg, 2 * HD, 0); else wgrad<R>(l.dzT, u, HD, HD, G + kGrnWg, 2 * HD, 0);
+    if (R == TMAX) wgrad32_mfma(l.dzT, gb.h2, G + kGrnWg, 2 * HD, HD); else wgrad<R>(l.dzT, gb.h2, HD, HD, G + kGrnWg, 2 * HD, HD);
     bgrad<R>(l.dzT, G + kGrnBg);
     // input gradients: 32-row tiles on the matrix pipe (staging tile = K | V | qs, dead once the attention backward is
     // done), the final GRN's single row on the VALU
@@ -503,7 +522,7 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     if (threadIdx.x < HD) G[kGrnBeta + o] = l.red[o] + l.red[HD + o] + l.red[2 * HD + o] + l.red[3 * HD + o];
     store_dz(l, tmp, act);
     __syncthreads();
-    wgrad<R>(l.dzT, gb.h1, HD, HD, G + kGrnW2, HD, 0);
+    if (R == TMAX) wgrad32_mfma(l.dzT, gb.h1, G + kGrnW2, HD, 0); else wgrad<R>(l.dzT, gb.h1, HD, HD, G + kGrnW2, HD, 0);
     bgrad<R>(l.dzT, G + kGrnB2);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) tmp[rr] = 0.0f;
@@ -516,7 +535,7 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     __syncthreads();
     store_dz(l, tmp, act);
     __syncthreads();
-    wgrad<R>(l.dzT, u, HD, HD, G + kGrnW1, HD, 0);
+    if (R == TMAX) wgrad32_mfma(l.dzT, u, G + kGrnW1, HD, 0); else wgrad<R>(l.dzT, u, HD, HD, G + kGrnW1, HD, 0);
     bgrad<R>(l.dzT, G + kGrnB1);
     if (WIDE) dense32_mfma(l.dz, Pg + kGrnW1, HD, stage, du);
     if (act) {
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
         const float ul = l.u[2][(T - 1) * HD + o];
         for (int oo = wv * 16; oo < wv * 16 + 16; ++oo) GA[kAttInW + oo * HD + o] = l.vec0[oo] * ul;
     }
-    wgrad<TMAX>(l.dzT, l.u[2], HD, HD, GA + kAttInW + HD * HD, HD, 0);  // key rows
+    wgrad32_mfma(l.dzT, l.u[2], GA + kAttInW + HD * HD, HD, 0);  // key rows
     bgrad<TMAX>(l.dzT, GA + kAttInB + HD);
     float du3[8];
 #pragma unroll
@@ -690,7 +709,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
         store_dz(l, dv, true);
     }
     __syncthreads();
-    wgrad<TMAX>(l.dzT, l.u[2], HD, HD, GA + kAttInW + 2 * HD * HD, HD, 0);  // value rows
+    wgrad32_mfma(l.dzT, l.u[2], GA + kAttInW + 2 * HD * HD, HD, 0);  // value rows
     bgrad<TMAX>(l.dzT, GA + kAttInB + 2 * HD);
     dense32_mfma(l.dz, A + kAttInW + 2 * HD * HD, HD, l.K, du3);           // + dV Wv
 #pragma unroll
