@@ -304,6 +304,63 @@ __device__ __forceinline__ float touch_params(const float* __restrict__ Pimg, in
 }
 __device__ __forceinline__ void keep(float v) { asm volatile("" ::"v"(v)); }
 
+// ---- GRN forward for a tile with ONE live row (the final GRN: tile row 0 <-> window row `row`) -----------------
+// The three matrix-vector products are split over the four waves (a quarter of k each, 16 or 32 weight loads in
+// flight per lane) and the partial sums meet in `red` [4][64]; every wave then holds the same row.  Rows 1..7 of the
+// stored buffers get neutral finite values (their upstream gradient is zero in the backward pass).
+template <int KQ>
+__device__ __forceinline__ float matvec_part(const float* vec, const float* __restrict__ Mat, int ld, int o, int k0) {
+    float wq[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) wq[k] = Mat[(k0 + k) * ld + o];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) s = fmaf(vec[k0 + k], wq[k], s);
+    return s;
+}
+__device__ __forceinline__ float cross_wave(float part, float bias, float* red) {
+    const int o = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    red[wv * HD + o] = part;
+    __syncthreads();
+    const float r = bias + ((red[o] + red[HD + o]) + (red[2 * HD + o] + red[3 * HD + o]));
+    __syncthreads();
+    return r;
+}
+template <bool TRAIN>
+__device__ __forceinline__ void grn_forward_row(const float* u, const GrnBuf& gb, float* out, const float* __restrict__ PT, const TftMasks& ms,
+                                                const Win& w, int which, int row, float* red) {
+    const int o = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    auto store8 = [&](float* buf, float live, float rest) {  // tile rows wv and wv + 4 of an [8][64] buffer
+        buf[wv * HD + o] = wv == 0 ? live : rest;
+        buf[(wv + 4) * HD + o] = rest;
+    };
+    float h1 = elu(cross_wave(matvec_part<16>(u, PT + kGrnW1, HD, o, 16 * wv), PT[kGrnB1 + o], red));
+    if (TRAIN && ms.mode != 0) h1 = keep_grn(ms, w, which, row, o) ? h1 * ms.scale : -0.0f;
+    store8(gb.h1, h1, -0.0f);
+    __syncthreads();
+    const float h2 = elu(cross_wave(matvec_part<16>(gb.h1, PT + kGrnW2, HD, o, 16 * wv), PT[kGrnB2 + o], red));
+    store8(gb.h2, h2, 0.0f);
+    __syncthreads();
+    // gate input = [u | h2] (transposed gate: [128][64]): waves 0-1 take u, waves 2-3 take h2
+    const float part = wv < 2 ? matvec_part<32>(u, PT + kGrnWg, HD, o, 32 * wv)
+                              : matvec_part<32>(gb.h2, PT + kGrnWg + HD * HD, HD, o, 32 * (wv - 2));
+    const float g = sigmoidf(cross_wave(part, PT[kGrnBg + o], red));
+    const float wgt = g * h2 + (1.0f - g) * u[o];
+    const float mean = wave_sum(wgt) * (1.0f / HD);
+    const float d = wgt - mean;
+    const float var = wave_sum(d * d) * (1.0f / HD);
+    const float rstd = 1.0f / sqrtf(var + kLnEps);
+    const float xh = d * rstd;
+    store8(gb.gt, g, 0.5f);
+    store8(gb.xh, xh, 0.0f);
+    if (o == 0) {
+        gb.rstd[wv] = wv == 0 ? rstd : 1.0f;
+        gb.rstd[wv + 4] = 1.0f;
+    }
+    store8(out, fmaf(xh, PT[kGrnGamma + o], PT[kGrnBeta + o]), 0.0f);
+    __syncthreads();
+}
+
 // ---- whole forward of one window; returns the prediction in every thread -----------------------------
 template <bool TRAIN>
 __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* __restrict__ xw, int64_t rows_left, int F, const float* __restrict__ P,
@@ -394,7 +451,7 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
     }
     __syncthreads();
     // final GRN on the last row (tile row 0 <-> window row T-1)
-    grn_forward<TRAIN, false>(l.a_out, l.g[2], l.out3, PT + tft_off_grn(F, 2), 1, ms, w, 2, T - 1, 1, nullptr);
+    grn_forward_row<TRAIN>(l.a_out, l.g[2], l.out3, PT + tft_off_grn(F, 2), ms, w, 2, T - 1, l.red);
     const float* Wo = P + tft_off_out(F);
     float y = wave_sum(l.out3[o] * Wo[o]) + Wo[HD];
     return y;
