@@ -323,6 +323,12 @@ int mcmc_flat_adamw(mcmc_ctx* ctx, float* param, int64_t n, const float* dP, int
                     float* adam_m, float* adam_v, double* norm_scratch, float lr, float beta1,
                     float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step,
                     float* gnorm, mcmc_stream_t stream);
+/* mcmc_flat_adamw on a TFT parameter vector P that also refreshes the transposed image PT in the same kernel
+ * (saves the mcmc_tft_transpose launch of every training step). */
+int mcmc_tft_adamw(mcmc_ctx* ctx, float* P, float* PT, int num_features, const float* dP, int n_partials,
+                   float* grad, float* adam_m, float* adam_v, double* norm_scratch, float lr, float beta1,
+                   float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step,
+                   float* gnorm, mcmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 11; }
+int mcmc_abi_version(void) { return 12; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -535,7 +535,20 @@ int mcmc_flat_adamw(mcmc_ctx* ctx, float* param, int64_t n, const float* dP, int
     MCMC_REQUIRE(step >= 1, "step is 1-based");
     MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
     return launch_flat_update(param, n, dP, n_partials, grad, adam_m, adam_v, norm_scratch, lr, beta1, beta2, adam_eps, weight_decay,
-                              max_norm, step, gnorm, (hipStream_t)stream);
+                              max_norm, step, gnorm, nullptr, 0, (hipStream_t)stream);
+}
+
+int mcmc_tft_adamw(mcmc_ctx* ctx, float* P, float* PT, int num_features, const float* dP, int n_partials, float* grad, float* adam_m,
+                   float* adam_v, double* norm_scratch, float lr, float beta1, float beta2, float adam_eps, float weight_decay,
+                   float max_norm, int64_t step, float* gnorm, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_tft(n_partials, 1, num_features)) return rc;
+    MCMC_REQUIRE(n_partials >= 1, "n_partials must be >= 1");
+    MCMC_REQUIRE(P && PT && dP && grad && adam_m && adam_v && norm_scratch, "NULL pointer");
+    MCMC_REQUIRE(step >= 1, "step is 1-based");
+    MCMC_REQUIRE(beta1 >= 0.0f && beta1 < 1.0f && beta2 >= 0.0f && beta2 < 1.0f, "betas must be in [0, 1)");
+    return launch_flat_update(P, mcmc_tft_param_count(num_features), dP, n_partials, grad, adam_m, adam_v, norm_scratch, lr, beta1, beta2,
+                              adam_eps, weight_decay, max_norm, step, gnorm, PT, num_features, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -604,33 +604,33 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------------
+// index of flat parameter i in the transposed image PT (every weight matrix [out][in] stored as [in][out]; vectors in place)
+__device__ __forceinline__ int tft_transposed_index(int i, int F) {
+    // find the matrix this element belongs to: (base, rows=out, cols=in) or a vector
+    int base = 0, rows = 0, cols = 0;
+    auto in_mat = [&](int b, int r, int c) {
+        if (i >= b && i < b + r * c) {
+            base = b;
+            rows = r;
+            cols = c;
+            return true;
+        }
+        return false;
+    };
+    bool m = in_mat(0, HD, F);
+    for (int g = 0; g < 3 && !m; ++g) {
+        const int gb = tft_off_grn(F, g);
+        m = in_mat(gb + kGrnW1, HD, HD) || in_mat(gb + kGrnW2, HD, HD) || in_mat(gb + kGrnWg, HD, 2 * HD);
+    }
+    if (!m) m = in_mat(tft_off_att(F) + kAttInW, 3 * HD, HD) || in_mat(tft_off_att(F) + kAttOutW, HD, HD);
+    if (!m) return i;
+    const int e = i - base, r = e / cols, c = e % cols;
+    return base + c * rows + r;
+}
+
 __global__ __launch_bounds__(256) void tft_transpose_kernel(const float* __restrict__ P, float* __restrict__ PT, int F) {
     const int n = tft_param_count(F);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        // find the matrix this element belongs to: (base, rows=out, cols=in) or a vector
-        int base = 0, rows = 0, cols = 0;
-        auto in_mat = [&](int b, int r, int c) {
-            if (i >= b && i < b + r * c) {
-                base = b;
-                rows = r;
-                cols = c;
-                return true;
-            }
-            return false;
-        };
-        bool m = in_mat(0, HD, F);
-        for (int g = 0; g < 3 && !m; ++g) {
-            const int gb = tft_off_grn(F, g);
-            m = in_mat(gb + kGrnW1, HD, HD) || in_mat(gb + kGrnW2, HD, HD) || in_mat(gb + kGrnWg, HD, 2 * HD);
-        }
-        if (!m) m = in_mat(tft_off_att(F) + kAttInW, 3 * HD, HD) || in_mat(tft_off_att(F) + kAttOutW, HD, HD);
-        int j = i;
-        if (m) {
-            const int e = i - base, r = e / cols, c = e % cols;
-            j = base + c * rows + r;
-        }
-        PT[j] = P[i];
-    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) PT[tft_transposed_index(i, F)] = P[i];
 }
 
 template <bool TRAIN>
@@ -820,7 +820,7 @@ struct FlatHyper {
 
 __global__ __launch_bounds__(256) void flat_adamw_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ am,
                                                         float* __restrict__ av, int64_t n, const double* __restrict__ normsq_part,
-                                                        int nparts, FlatHyper hp, float* __restrict__ gnorm) {
+                                                        int nparts, FlatHyper hp, float* __restrict__ gnorm, float* __restrict__ PT, int F) {
     // squared norm from the per-block partials (nparts <= 256): one partial per thread, a fixed shuffle tree per wave,
     // then the four wave sums in order - the same value in every workgroup and every run
     __shared__ double wsum[4];
@@ -843,6 +843,7 @@ __global__ __launch_bounds__(256) void flat_adamw_kernel(float* __restrict__ par
         av[i] = vv;
         p -= (hp.lr / hp.bias1) * (mm / (sqrtf(vv) / hp.bias2_sqrt + hp.eps));
         param[i] = p;
+        if (PT) PT[tft_transposed_index((int)i, F)] = p;  // the TFT's transposed image stays in step with the parameters
     }
 }
 
@@ -904,7 +905,7 @@ int launch_tft_backward(const float* X, int64_t n_rows, const int* start, int B,
 
 int launch_flat_update(float* param, int64_t n, const float* dP, int B, float* grad, float* am, float* av, double* normsq_part, float lr,
                        float beta1, float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm,
-                       hipStream_t s) {
+                       float* PT, int F, hipStream_t s) {
     hipLaunchKernelGGL(flat_grad_kernel, dim3(kFlatBlocks), dim3(256), 0, s, dP, B, n, grad, normsq_part);
     FlatHyper hp;
     hp.lr = lr;
@@ -915,7 +916,7 @@ int launch_flat_update(float* param, int64_t n, const float* dP, int B, float* g
     hp.max_norm = max_norm;
     hp.bias1 = (float)(1.0 - pow((double)beta1, (double)step));
     hp.bias2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-    hipLaunchKernelGGL(flat_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, am, av, n, normsq_part, kFlatBlocks, hp, gnorm);
+    hipLaunchKernelGGL(flat_adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, am, av, n, normsq_part, kFlatBlocks, hp, gnorm, PT, F);
     return check_launch("flat_update");
 }
 

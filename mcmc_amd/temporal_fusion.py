@@ -173,10 +173,10 @@ class TFTEngine:
                    "mcmc_tft_backward_saved")
         if update:
             self.t += 1
-            _lib.check(self.lib.mcmc_flat_adamw(self.h, _p(self.P), self.n, _p(self.dP), B, _p(self.grad), _p(self.adam_m),
-                                                _p(self.adam_v), _p(self.norm_scratch), lr, beta1, self.beta2, self.adam_eps,
-                                                self.weight_decay, self.max_norm, self.t, _p(self.gnorm), st), "mcmc_flat_adamw")
-            self._pt_stale = True
+            # clip + AdamW; the same kernel refreshes the transposed image PT (it was current: _transpose() above)
+            _lib.check(self.lib.mcmc_tft_adamw(self.h, _p(self.P), _p(self.PT), self.F, _p(self.dP), B, _p(self.grad), _p(self.adam_m),
+                                               _p(self.adam_v), _p(self.norm_scratch), lr, beta1, self.beta2, self.adam_eps,
+                                               self.weight_decay, self.max_norm, self.t, _p(self.gnorm), st), "mcmc_tft_adamw")
         return self.loss
 
 

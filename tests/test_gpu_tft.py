@@ -143,6 +143,11 @@ def test_tft_saved_activations_equal_recompute(golden):
                                          _p(dP), st), "b")
         assert torch.equal(te.pred[:n_win], pred) and torch.equal(loss, l2)
         assert torch.equal(te.dP[:n_win], dP)
+    # an updating step keeps the transposed image in step with the parameters (mcmc_tft_adamw writes both)
+    te.step(X, start, yb, 1e-3, 0.9, seed=5)
+    fresh = torch.empty_like(te.PT)
+    _lib.check(lib.mcmc_tft_transpose(h, _p(te.P), _p(fresh), F, _stream()), "t")
+    assert torch.equal(te.PT, fresh) and not torch.equal(te.P.cpu(), torch.from_numpy(z["flat"]))
 
 
 def test_tft_model_trains_and_predicts_end_to_end(golden):
