@@ -186,6 +186,11 @@ int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_d
 int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples,
                     int64_t rows, float alpha, float beta, float* delta, float* loss,
                     mcmc_stream_t stream);
+/* mcmc_train_loss that also adds every member's loss to loss_acc (fp64 [M]): the epoch sums of
+ * bayesian_ensemble.py:181 / temporal_fusion.py:257 kept on the device. */
+int mcmc_train_loss_acc(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples,
+                        int64_t rows, float alpha, float beta, float* delta, float* loss,
+                        double* loss_acc, mcmc_stream_t stream);
 /* Backward of every pair (recomputes its forward with the same masks): dW (loss.backward, :178). */
 int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim,
                         int n_members, int n_samples, const float* W, const float* WT,

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16 = 0, 1
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class MCMCLibraryError(RuntimeError):
@@ -96,6 +96,7 @@ SIGNATURES = {
     "mcmc_tft_backward": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr,
                                  _stream]),
     "mcmc_flat_norm_blocks": (_i32, []),
+    "mcmc_train_loss_acc": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i64, _f32, _f32, _ptr, _ptr, _ptr, _stream]),
     "mcmc_tft_adamw": (_i32, [_ctx_p, _ptr, _ptr, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _ptr,
                               _stream]),
     "mcmc_flat_adamw": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _ptr,

@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 12; }
+int mcmc_abi_version(void) { return 13; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -319,6 +319,14 @@ int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_member
     if (int rc = check_train(n_members, n_samples, 1, rows)) return rc;
     MCMC_REQUIRE(Y && yb && delta && loss, "NULL pointer");
     return launch_train_loss(Y, yb, rows, n_members, n_samples, rows, alpha, beta, delta, loss, nullptr, (hipStream_t)stream);
+}
+
+int mcmc_train_loss_acc(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples, int64_t rows, float alpha,
+                        float beta, float* delta, float* loss, double* loss_acc, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, 1, rows)) return rc;
+    MCMC_REQUIRE(Y && yb && delta && loss && loss_acc, "NULL pointer");
+    return launch_train_loss(Y, yb, rows, n_members, n_samples, rows, alpha, beta, delta, loss, loss_acc, (hipStream_t)stream);
 }
 
 static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,

@@ -151,8 +151,9 @@ class TFTEngine:
 
     def step(self, X: torch.Tensor, start: torch.Tensor, yb: torch.Tensor, lr: float, beta1: float = 0.9, *,
              masks: Optional[Sequence[torch.Tensor]] = None, seed: int = 0, alpha: float = 2.0, beta: float = 0.5,
-             update: bool = True) -> torch.Tensor:
-        """One optimisation step (temporal_fusion.py:247-256) on the windows ``start``; returns the loss [1] (device)."""
+             update: bool = True, loss_acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One optimisation step (temporal_fusion.py:247-256) on the windows ``start``; returns the loss [1] (device).
+        ``loss_acc``: optional fp64 [1] on the device, loss_acc += loss (the epoch sum of :257)."""
         self._check(X, start)
         B = start.numel()
         if B > self.max_windows:
@@ -166,8 +167,14 @@ class TFTEngine:
         pred = self.pred
         _lib.check(self.lib.mcmc_tft_forward_save(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
                                                   seed & _U64, self.p_drop, _p(pred), _p(self.act), st), "mcmc_tft_forward_save")
-        _lib.check(self.lib.mcmc_train_loss(self.h, _p(pred), _p(yb), 1, 1, B, alpha, beta, _p(self.delta), _p(self.loss), st),
-                   "mcmc_train_loss")
+        if loss_acc is None:
+            _lib.check(self.lib.mcmc_train_loss(self.h, _p(pred), _p(yb), 1, 1, B, alpha, beta, _p(self.delta), _p(self.loss), st),
+                       "mcmc_train_loss")
+        else:
+            if loss_acc.dtype != torch.float64 or loss_acc.numel() != 1 or not loss_acc.is_cuda:
+                raise ValueError("loss_acc must be an fp64 [1] device tensor")
+            _lib.check(self.lib.mcmc_train_loss_acc(self.h, _p(pred), _p(yb), 1, 1, B, alpha, beta, _p(self.delta), _p(self.loss),
+                                                    _p(loss_acc), st), "mcmc_train_loss_acc")
         _lib.check(self.lib.mcmc_tft_backward_saved(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
                                                     seed & _U64, self.p_drop, _p(self.delta), _p(self.dP), _p(self.act), st),
                    "mcmc_tft_backward_saved")
@@ -232,8 +239,7 @@ class TFTModel:
             targets = yd[perm.long() + (self.seq_length - 1)]
             epoch_loss = torch.zeros(1, dtype=torch.float64, device=dev)
             for (b0, b1) in bounds:
-                loss = te.step(Xd, perm[b0:b1].contiguous(), targets[b0:b1], lrs[it], b1s[it], seed=(seed0 + _GOLDEN * (it + 1)) & _U64)
-                epoch_loss += loss.double()
+                te.step(Xd, perm[b0:b1], targets[b0:b1], lrs[it], b1s[it], seed=(seed0 + _GOLDEN * (it + 1)) & _U64, loss_acc=epoch_loss)
                 it += 1
             self.epochs_trained = epoch + 1
             epoch_loss = float(epoch_loss.item())  # one sync per epoch
