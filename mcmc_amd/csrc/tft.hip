@@ -603,6 +603,54 @@ __device__ __forceinline__ void grn_backward(const Lds& l, const float* u, const
     __syncthreads();
 }
 
+// GRN backward for a tile with ONE live row (the final GRN): upstream l.dU row 0 -> l.dU row 0.  Weight gradients are
+// outer products (wave wv writes output rows 16*wv..), the four input-gradient products are matrix-vector products
+// split over the four waves like grn_forward_row.  `vec` = 64 floats of LDS scratch.
+__device__ __forceinline__ void grn_backward_row(const Lds& l, const float* u, const GrnBuf& gb, const float* __restrict__ Pg,
+                                                 float* __restrict__ G, float scale, float* vec) {
+    const int o = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float dy = l.dU[o], xh = gb.xh[o];
+    const float dxh = dy * Pg[kGrnGamma + o];
+    const float m1 = wave_sum(dxh) * (1.0f / HD);
+    const float m2 = wave_sum(dxh * xh) * (1.0f / HD);
+    const float dw = gb.rstd[0] * (dxh - m1 - xh * m2);
+    const float g = gb.gt[o], h2v = gb.h2[o], uv = u[o], h1v = gb.h1[o];
+    const float dgp = dw * (h2v - uv) * g * (1.0f - g);  // d gate pre-activation
+    float dh2 = dw * g, du = dw * (1.0f - g);
+    if (wv == 0) {
+        G[kGrnGamma + o] = dy * xh;
+        G[kGrnBeta + o] = dy;
+        G[kGrnBg + o] = dgp;
+        vec[o] = dgp;
+    }
+    __syncthreads();
+    // gate: dWg[oo][k] = dgp[oo] [u | h2][k];  d[u | h2] += dgp Wg
+    for (int oo = 16 * wv; oo < 16 * wv + 16; ++oo) {
+        const float d = vec[oo];
+        G[kGrnWg + oo * 2 * HD + o] = d * uv;
+        G[kGrnWg + oo * 2 * HD + HD + o] = d * h2v;
+    }
+    du += cross_wave(matvec_part<16>(vec, Pg + kGrnWg, 2 * HD, o, 16 * wv), 0.0f, l.red);
+    dh2 += cross_wave(matvec_part<16>(vec, Pg + kGrnWg + HD, 2 * HD, o, 16 * wv), 0.0f, l.red);
+    const float da2 = dh2 * (h2v > 0.0f ? 1.0f : h2v + 1.0f);
+    if (wv == 0) {
+        G[kGrnB2 + o] = da2;
+        vec[o] = da2;  // every wave finished reading vec before cross_wave's barriers
+    }
+    __syncthreads();
+    for (int oo = 16 * wv; oo < 16 * wv + 16; ++oo) G[kGrnW2 + oo * HD + o] = vec[oo] * h1v;
+    const float da1 = cross_wave(matvec_part<16>(vec, Pg + kGrnW2, HD, o, 16 * wv), 0.0f, l.red) * dfactor(h1v, scale);
+    if (wv == 0) {
+        G[kGrnB1 + o] = da1;
+        vec[o] = da1;
+    }
+    __syncthreads();
+    for (int oo = 16 * wv; oo < 16 * wv + 16; ++oo) G[kGrnW1 + oo * HD + o] = vec[oo] * uv;
+    du += cross_wave(matvec_part<16>(vec, Pg + kGrnW1, HD, o, 16 * wv), 0.0f, l.red);
+    if (wv == 0) l.dU[o] = du;
+    __syncthreads();
+}
+
 // ---- kernels ---------------------------------------------------------------------------------------------------
 // index of flat parameter i in the transposed image PT (every weight matrix [out][in] stored as [in][out]; vectors in place)
 __device__ __forceinline__ int tft_transposed_index(int i, int F) {
@@ -692,7 +740,7 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
         for (int i = t; i < TMAX * HD; i += NT) l.dU[i] = i < HD ? dy * Wo[i] : 0.0f;
     }
     __syncthreads();
-    grn_backward<8>(l, l.a_out, l.g[2], P + tft_off_grn(F, 2), G + tft_off_grn(F, 2), 1, sc);
+    grn_backward_row(l, l.a_out, l.g[2], P + tft_off_grn(F, 2), G + tft_off_grn(F, 2), sc, l.vec1);
     // ---- attention backward; l.dU row 0 = gradient w.r.t. the attention output of the last row
     const float* A = P + tft_off_att(F);
     float* GA = G + tft_off_att(F);
