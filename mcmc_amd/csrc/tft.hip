@@ -97,21 +97,6 @@ __device__ __forceinline__ void dense8(const float* in, int stride, int row0, co
     }
 }
 
-// s + sum_{k<N} vec[k] * Mat[k*ld + c], k ascending (`vec` in LDS, Mat in global memory): the loads of 16 k are
-// issued together - a plain loop waits one L2 round trip per k
-template <int N>
-__device__ __forceinline__ float dot_col(const float* vec, const float* __restrict__ Mat, int ld, int c, float s) {
-#pragma unroll 1
-    for (int k0 = 0; k0 < N; k0 += 16) {
-        float w[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) w[k] = Mat[(k0 + k) * ld + c];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) s = fmaf(vec[k0 + k], w[k], s);
-    }
-    return s;
-}
-
 // The same product as dense8<64> for ALL 32 rows of a tile on the matrix pipe (v_mfma_f32_32x32x2_f32: exact fp32
 // FMAs): acc[rr] += sum_{j<64} in[(8*wave+rr)*64 + j] * Mat[j*ld + lane].  Every wave of the workgroup takes part:
 // wave = (mo, kh) computes output features 32*mo.. for k = 32*kh..32*kh+31 (16 MFMAs, its 16 weight loads in flight
@@ -407,10 +392,9 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
         dense32_mfma(l.u[2], A + kAttInW + 2 * HD, 3 * HD, l.dU, acc);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) l.V[(r0 + rr) * HD + o] = r0 + rr < T ? acc[rr] : 0.0f;
-        if (wv == 0) {
-            const float q = dot_col<HD>(l.u[2] + (T - 1) * HD, A + kAttInW, 3 * HD, o, A[kAttInB + o]);
-            l.qs[o] = q * 0.25f;  // q * sqrt(1/head_dim), head_dim = 16
-        }
+        // query of the last row: a matrix-vector product split over the four waves
+        const float q = cross_wave(matvec_part<16>(l.u[2] + (T - 1) * HD, A + kAttInW, 3 * HD, o, 16 * wv), A[kAttInB + o], l.red);
+        if (wv == 0) l.qs[o] = q * 0.25f;  // q * sqrt(1/head_dim), head_dim = 16
     }
     __syncthreads();
     if (t < NH * TMAX) {  // scores + softmax: 32 lanes per head
@@ -442,12 +426,11 @@ __device__ __forceinline__ float tft_forward_window(const Lds& l, const float* _
         l.ctx[t] = c;
     }
     __syncthreads();
-    for (int i = t; i < 8 * HD; i += NT) {
-        float v = 0.0f;
-        if (i < HD) {
-            v = dot_col<HD>(l.ctx, A + kAttOutW, HD, i, A[kAttOutB + i]);
-        }
-        l.a_out[i] = v;
+    {  // attention output projection of the last row -> tile row 0 of a_out, rows 1..7 zero
+        const float ao = cross_wave(matvec_part<16>(l.ctx, A + kAttOutW, HD, o, 16 * wv), A[kAttOutB + o], l.red);
+        static_assert(8 * HD == 2 * NT, "a_out is written as two elements per thread");
+        l.a_out[t] = wv == 0 ? ao : 0.0f;
+        l.a_out[t + NT] = 0.0f;
     }
     __syncthreads();
     // final GRN on the last row (tile row 0 <-> window row T-1)
@@ -753,9 +736,8 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     {  // dWo[o][c] = do[o] ctx[c];  dctx[c] = sum_o do[o] Wo[o][c]
         const float c = l.ctx[o];
         for (int oo = wv * 16; oo < wv * 16 + 16; ++oo) GA[kAttOutW + oo * HD + o] = l.vec0[oo] * c;
-        if (wv == 0) {
-            l.vec1[o] = dot_col<HD>(l.vec0, A + kAttOutW, HD, o, 0.0f);  // dctx
-        }
+        const float dc = cross_wave(matvec_part<16>(l.vec0, A + kAttOutW, HD, o, 16 * wv), 0.0f, l.red);
+        if (wv == 0) l.vec1[o] = dc;  // dctx
     }
     __syncthreads();
     if (t < NH * TMAX) {  // softmax backward, 32 lanes per head
@@ -799,8 +781,8 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) du3[rr] = 0.0f;
     dense32_mfma(l.dz, A + kAttInW + HD * HD, HD, l.K, du3);           // dK Wk (K, V, qs are dead: staging tile)
+    const float s = cross_wave(matvec_part<16>(l.vec0, A + kAttInW, HD, o, 16 * wv), 0.0f, l.red);
     if (wv == (T - 1) / 8) {                                          // + Wq^T dq on the last row
-        const float s = dot_col<HD>(l.vec0, A + kAttInW, HD, o, 0.0f);
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr)
             if (r0 + rr == T - 1) du3[rr] += s;
