@@ -77,6 +77,42 @@ def test_tft_train_forward_loss_and_gradient_match_oracle(golden, step):
     np.testing.assert_allclose(te.gnorm.item(), total.item(), rtol=3e-5)
 
 
+@pytest.mark.parametrize("F,T,B", [(5, 12, 7), (24, 30, 3), (1, 2, 32), (11, 32, 5)])
+def test_tft_other_widths_and_window_lengths(F, T, B):
+    """Feature counts across the input-projection range and short / full-tile windows (the MFMA tiles always span 32 rows:
+    rows past seq_len must stay inert): eval forward, loss and every parameter gradient against the oracle's autograd."""
+    g = torch.Generator().manual_seed(100 * F + T)
+    flat = torch.cat([(torch.randn(int(np.prod(sh)), generator=g) * (0.15 if len(sh) > 1 else 0.05)) + (1.0 if n.endswith("layer_norm.weight") else 0.0)
+                      for n, sh in tft.param_spec(F)])
+    xb = torch.randn(B, T, F, generator=g)
+    yb = torch.randn(B, generator=g)
+    o = tft.TFTTrainOracle(flat.clone(), F)
+    loss, grad, total, pred = o.step(xb, yb, None, lr=1e-3, beta1=0.9)   # masks None: dropout off
+    te = _engine(flat.numpy(), F, T)
+    X, start = _windows(xb)
+    np.testing.assert_allclose(te.forward(X, start).cpu().numpy(), pred.numpy(), rtol=0, atol=2e-5)
+    # eval-mode step: no masks, no seed-driven dropout -> host masks of ones
+    ones = [torch.ones(B, T, 64, dtype=torch.uint8), torch.ones(B, T, 64, dtype=torch.uint8), torch.ones(B * 4, T, T, dtype=torch.uint8),
+            torch.ones(B, T, 64, dtype=torch.uint8)]
+    te.p_drop = 0.0
+    got_loss = te.step(X, start, yb.to(DEV), 1e-3, 0.9, masks=ones, update=False).cpu()
+    np.testing.assert_allclose(got_loss.item(), loss.item(), rtol=5e-5)
+    from mcmc_amd import _lib
+    from mcmc_amd.engine import _p, _stream
+    _lib.check(te.lib.mcmc_flat_adamw(te.h, _p(te.P.clone()), te.n, _p(te.dP), B, _p(te.grad), _p(te.adam_m.clone()), _p(te.adam_v.clone()),
+                                      _p(te.norm_scratch), 1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 1, _p(te.gnorm), _stream()), "adamw")
+    gg, ref = te.grad.cpu().numpy(), grad.numpy()
+    off = 0
+    for name, shape in tft.param_spec(F):
+        k = int(np.prod(shape))
+        a, b = gg[off:off + k], ref[off:off + k]
+        if name == "attention.in_proj_bias":
+            a, b = np.concatenate([a[:64], a[128:]]), np.concatenate([b[:64], b[128:]])
+        scale = max(np.abs(b).max(), 1e-6)
+        assert np.abs(a - b).max() <= 5e-5 * scale + 1e-7, (name, np.abs(a - b).max(), scale)
+        off += k
+
+
 def test_tft_replays_reference_trajectory(golden):
     z = golden("tft_train.npz")
     F = z["X"].shape[1]
