@@ -30,6 +30,31 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
 
 
+def test_ctypes_structs_and_arities_follow_the_header():
+    """The ctypes mirrors of the header's structs list the same fields in the same order with the same C types, and every
+    bound signature has as many arguments as its declaration."""
+    import ctypes
+    from mcmc_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mcmc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for cname, mirror in (("mcmc_train_buffers", _lib.TrainBuffers), ("mcmc_train_hyper", _lib.TrainHyper)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), text, flags=re.S).group(1)
+        fields = []
+        for decl in filter(None, (d.strip() for d in body.split(";"))):
+            ctype, names = re.match(r"((?:const\s+)?[a-z0-9_]+\s*\*?)\s*(.*)", decl).groups()
+            for nm in names.split(","):
+                nm = nm.strip()
+                ptr = "*" in ctype or nm.startswith("*")
+                base = ctype.replace("*", "").replace("const", "").strip()
+                fields.append((nm.lstrip("* "), ctypes.c_void_p if ptr else {"float": ctypes.c_float, "int64_t": ctypes.c_int64,
+                                                                              "int": ctypes.c_int}[base]))
+        assert [(n, t) for n, t in mirror._fields_] == fields, cname
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        decl = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, text, flags=re.S).group(1).strip()
+        n_args = 0 if decl in ("", "void") else decl.count(",") + 1
+        assert len(argtypes) == n_args, (name, len(argtypes), n_args)
+
+
 def test_layout_queries_without_gpu():
     from mcmc_amd import _lib
     from mcmc_amd.engine import param_count
