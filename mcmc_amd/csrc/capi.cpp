@@ -23,7 +23,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 static int check_dims(int input_dim, int dtype) {
     MCMC_REQUIRE(input_dim >= 1 && input_dim <= kMaxInputDim, "input_dim must be in [1, %d] (got %d)", kMaxInputDim, input_dim);
-    MCMC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16, "dtype must be MCMC_DT_F32 or MCMC_DT_BF16 (got %d)", dtype);
+    MCMC_REQUIRE(dtype == DT_F32 || dtype == DT_BF16 || dtype == DT_BF16_FAST, "dtype must be MCMC_DT_F32, MCMC_DT_BF16 or MCMC_DT_BF16_FAST (got %d)", dtype);
     return MCMC_OK;
 }
 
@@ -79,7 +79,7 @@ int64_t mcmc_xpack_bytes(int64_t n_rows, int input_dim, int dtype) {
 
 int64_t mcmc_wpack_bytes(int input_dim, int dtype) {
     if (int rc = check_dims(input_dim, dtype)) return rc;
-    return dtype == DT_F32 ? WPackF32(input_dim).total * 4 : WPackBF16(input_dim).total;
+    return dtype == DT_F32 ? WPackF32(input_dim).total * 4 : dtype == DT_BF16 ? WPackBF16(input_dim).total : WPackBF16F(input_dim).total;
 }
 
 int mcmc_pack_x(mcmc_ctx* ctx, const float* X, int64_t n_rows, int input_dim, int dtype, void* xpack, mcmc_stream_t stream) {
@@ -145,7 +145,7 @@ static int forward_impl(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_r
     MCMC_REQUIRE(ldY >= n_rows && ldY % 4 == 0, "ldY must be >= n_rows and a multiple of 4 (got %lld)", (long long)ldY);
     if (dtype == DT_F32)
         return launch_forward_f32((const float*)xpack, n_rows, input_dim, (const float*)wpack, pair_count, dm, Y, ldY, (hipStream_t)stream);
-    return launch_forward_bf16(ctx, xpack, n_rows, input_dim, wpack, pair_count, dm, Y, ldY, (hipStream_t)stream);
+    return launch_forward_bf16(ctx, dtype == DT_BF16_FAST, xpack, n_rows, input_dim, wpack, pair_count, dm, Y, ldY, (hipStream_t)stream);
 }
 
 int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int pair_count,

@@ -51,7 +51,7 @@ int launch_philox_eps(uint64_t seed, int64_t g_begin, int pair_count, int F, flo
 struct DropMask;  // dropmask.hpp; NULL or mode 0 = eval-mode forward
 int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* wpack, int pair_count, const DropMask* dm, float* Y,
                        int64_t ldY, hipStream_t s);
-int launch_forward_bf16(const mcmc_ctx* ctx, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
+int launch_forward_bf16(const mcmc_ctx* ctx, bool fast, const void* xpack, int64_t n_rows, int F, const void* wpack, int pair_count,
                         const DropMask* dm, float* Y, int64_t ldY, hipStream_t s);
 int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
                          double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s);

@@ -12,7 +12,6 @@ namespace mcmc {
 
 namespace {
 
-constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 struct NoiseSrc {
@@ -206,6 +205,98 @@ __global__ __launch_bounds__(256) void sample_weights_bf16_kernel(NoiseSrc ns, i
     }
 }
 
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
+// sum over one weight row of the bf16 values the MFMA will multiply by (n % 4 == 0, row_off % 4 == 0)
+__device__ __forceinline__ float rowsum_bf16(const NoiseSrc& ns, int m, uint32_t g, int64_t row_off, int n, float scale) {
+    float s = 0.0f;
+    for (int k = 0; k < n; k += 4) {
+        float w[4];
+        effective_weight4(ns, m, g, row_off + k, w);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s += bf16_round(w[t] * scale);
+    }
+    return s;
+}
+
+// The MCMC_DT_BF16_FAST image in the shifted log2e domain (layout.hpp, forward_bf16.hip): hidden accumulators hold
+// c*z + c and activations c*(elu + 1), so every bias also carries c*(1 - rowsum of its bf16 weight row).
+__global__ __launch_bounds__(256) void sample_weights_bf16_fast_kernel(NoiseSrc ns, int M, int S, int F, int64_t pair_begin,
+                                                                       uint32_t* __restrict__ wpack) {
+    const WPackBF16F L(F);
+    const int c = blockIdx.y;
+    const int64_t q = pair_begin + c;
+    const int m = (int)(q % M);
+    const uint32_t g = (uint32_t)((int64_t)m * S + q / M);
+    uint32_t* out = wpack + (int64_t)c * (L.total / 4);
+    const int ks0 = L.K0 / 16;
+    const int64_t ndw = L.total / 4;
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndw; d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t byte = d * 4;
+        uint32_t word = 0;
+        if (byte < L.l1) {
+            // layer 0: two consecutive bf16 elements j, j+1 of one lane's 8-element fragment
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t el = byte / 2 + u;
+                const int j = (int)(el & 7), lane = (int)((el >> 3) & 63);
+                const int step = (int)((el >> 9) % ks0), mo = (int)((el >> 9) / ks0);
+                const int o = 32 * mo + (lane & 31), k = 16 * step + 8 * (lane >> 5) + j;
+                if (k < F) {
+                    v[u] = effective_weight(ns, m, g, (int64_t)o * F + k) * kLog2e;
+                } else if (k == F || (k == F + 1 && L.bias_residual)) {
+                    const float b = fmaf(effective_weight(ns, m, g, flat_b_off(F, 0) + o), kLog2e, kLog2e);
+                    v[u] = k == F ? b : b - bf16_round(b);
+                } else {
+                    v[u] = 0.0f;
+                }
+            }
+            word = bf16_bits(v[0]) | (bf16_bits(v[1]) << 16);
+        } else if (byte < L.l3) {
+            // layers 1-2: elements j..j+3 (j = 0 or 4) of a lane's fragment are four consecutive k of one
+            // weight row = one Philox block; the even dword of each 8-byte unit produces both dwords
+            if (d & 1) continue;
+            const int64_t el = byte / 2;
+            int64_t idx0;
+            if (byte < L.l2) {
+                const int64_t l = el - L.l1 / 2;
+                const int j = (int)(l & 7), lane = (int)((l >> 3) & 63), step = (int)((l >> 9) & 15), mo = (int)(l >> 13);
+                idx0 = flat_w_off(F, 1) + (int64_t)(32 * mo + (lane & 31)) * H1 + kperm_bf16(step >> 1, step & 1, lane >> 5, j);
+            } else {
+                const int64_t l = el - L.l2 / 2;
+                const int j = (int)(l & 7), lane = (int)((l >> 3) & 63), step = (int)((l >> 9) & 7), mo = (int)(l >> 12);
+                idx0 = flat_w_off(F, 2) + (int64_t)(32 * mo + (lane & 31)) * H2 + kperm_bf16(step >> 1, step & 1, lane >> 5, j);
+            }
+            float w[4];
+            effective_weight4(ns, m, g, idx0, w);
+            out[d] = bf16_bits(w[0]) | (bf16_bits(w[1]) << 16);
+            out[d + 1] = bf16_bits(w[2]) | (bf16_bits(w[3]) << 16);
+            continue;
+        } else if (byte < L.b1) {
+            // layer 3: output row 0 of a 32-row A tile (lanes 0 and 32), the other rows stay zero
+            const int64_t l = (byte - L.l3) / 2;
+            const int j = (int)(l & 7), lane = (int)((l >> 3) & 63), step = (int)(l >> 9);
+            if ((lane & 31) == 0) {
+                const int64_t idx = flat_w_off(F, 3) + kperm_bf16(step >> 1, step & 1, lane >> 5, j);
+                word = bf16_bits(effective_weight(ns, m, g, idx) * kLn2) | (bf16_bits(effective_weight(ns, m, g, idx + 1) * kLn2) << 16);
+            }
+        } else if (byte < L.b3) {
+            const bool first = byte < L.b2;
+            const int l = (int)((byte - (first ? L.b1 : L.b2)) / 4);
+            const int o = 32 * (l >> 5) + acc_feature(l & 15, (l >> 4) & 1);
+            const int layer = first ? 1 : 2, n_in = first ? H1 : H2;
+            const float b = effective_weight(ns, m, g, flat_b_off(F, layer) + o);
+            const float rs = rowsum_bf16(ns, m, g, flat_w_off(F, layer) + (int64_t)o * n_in, n_in, 1.0f);
+            word = __float_as_uint(kLog2e * (b + 1.0f - rs));
+        } else if (byte == L.b3) {
+            const float b = effective_weight(ns, m, g, flat_b_off(F, 3));
+            word = __float_as_uint(fmaf(-kLog2e, rowsum_bf16(ns, m, g, flat_w_off(F, 3), H3, kLn2), b));
+        }
+        out[d] = word;
+    }
+}
+
 __global__ __launch_bounds__(256) void philox_eps_kernel(uint64_t seed, int64_t g_begin, int64_t P, float* __restrict__ eps) {
     const uint32_t g = (uint32_t)(g_begin + blockIdx.y);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x)
@@ -224,14 +315,14 @@ __global__ __launch_bounds__(256) void pack_x_f32_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void pack_x_bf16_kernel(const float* __restrict__ X, int64_t n_rows, int F, int K0,
+__global__ __launch_bounds__(256) void pack_x_bf16_kernel(const float* __restrict__ X, int64_t n_rows, int F, int K0, bool residual_col,
                                                           unsigned short* __restrict__ xp) {
     const int64_t total = rows_pad(n_rows) * K0;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = e / K0;
         const int k = (int)(e % K0);
         float v = 0.0f;
-        if (row < n_rows) v = k < F ? X[row * F + k] : (k == F ? 1.0f : 0.0f);
+        if (row < n_rows) v = k < F ? X[row * F + k] : ((k == F || (k == F + 1 && residual_col)) ? 1.0f : 0.0f);
         xp[e] = (unsigned short)bf16_bits(v);
     }
 }
@@ -250,7 +341,7 @@ int launch_pack_x(const float* X, int64_t n_rows, int F, int dtype, void* xpack,
         hipLaunchKernelGGL(pack_x_f32_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, s, X, n_rows, F, K0, (float*)xpack);
     else
         hipLaunchKernelGGL(pack_x_bf16_kernel, dim3(grid_for(total, 4096)), dim3(256), 0, s, X, n_rows, F, K0,
-                           (unsigned short*)xpack);
+                           dtype == DT_BF16_FAST && WPackBF16F(F).bias_residual, (unsigned short*)xpack);
     return check_launch("pack_x");
 }
 
@@ -265,9 +356,13 @@ int launch_sample_weights(const float* mu, const float* rho, int M, int S, int F
             const WPackF32 L(F);
             hipLaunchKernelGGL(sample_weights_f32_kernel, dim3(grid_for(L.total, 64), n), dim3(256), 0, s, ns, M, S, F,
                                pair_begin + done, (float*)wpack + (int64_t)done * L.total);
-        } else {
+        } else if (dtype == DT_BF16) {
             const WPackBF16 L(F);
             hipLaunchKernelGGL(sample_weights_bf16_kernel, dim3(grid_for(L.total / 4, 32), n), dim3(256), 0, s, ns, M, S, F,
+                               pair_begin + done, (uint32_t*)wpack + (int64_t)done * (L.total / 4));
+        } else {
+            const WPackBF16F L(F);
+            hipLaunchKernelGGL(sample_weights_bf16_fast_kernel, dim3(grid_for(L.total / 4, 32), n), dim3(256), 0, s, ns, M, S, F,
                                pair_begin + done, (uint32_t*)wpack + (int64_t)done * (L.total / 4));
         }
         done += n;

@@ -19,18 +19,19 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import DT_BF16, DT_F32, NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX
+from ._lib import DT_BF16, DT_BF16_FAST, DT_F32, NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX
 
 HIDDEN = (256, 128, 64)
 _DTYPES = {"fp32": DT_F32, "f32": DT_F32, "float32": DT_F32, torch.float32: DT_F32,
-           "bf16": DT_BF16, "bfloat16": DT_BF16, torch.bfloat16: DT_BF16}
+           "bf16": DT_BF16, "bfloat16": DT_BF16, torch.bfloat16: DT_BF16,
+           "bf16_fast": DT_BF16_FAST}
 
 
 def resolve_dtype(dtype) -> int:
     try:
         return _DTYPES[dtype]
     except KeyError:
-        raise ValueError(f"dtype must be 'fp32' or 'bf16', got {dtype!r}") from None
+        raise ValueError(f"dtype must be 'fp32', 'bf16' or 'bf16_fast', got {dtype!r}") from None
 
 
 def param_count(input_dim: int) -> int:
@@ -376,7 +377,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                mask_seed: Optional[int] = None) -> PredictResult:
     """Monte Carlo predictive statistics of the ensemble over X.
 
-    X [B,F] fp32 on a HIP device; mu, rho [M,P] fp32 (pack_members).  noise: 'philox'
+    X [B,F] fp32 on a HIP device; mu, rho [M,P] fp32 (pack_members).  dtype: 'fp32' (the parity path), 'bf16'
+    (bf16 MFMA operands, exact ELU) or 'bf16_fast' (bf16 operands, exponent-field ELU: include/mcmc_hip.h).  noise: 'philox'
     (counter-based, keyed by seed and the global pair id: independent of chunking and world
     size), 'injected' (eps [M*S,P] fp32 in the reference's draw order) or 'none' (sample=False).
     With torch.distributed initialised (backend 'nccl' = RCCL), the M*S pairs are sharded over
@@ -402,6 +404,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     S = int(num_samples)
     if S < 1:
         raise ValueError("num_samples must be >= 1")
+    if mc_dropout and dt == DT_BF16_FAST:
+        raise ValueError("dtype 'bf16_fast' is the eval-mode predict only (no dropout-mask stage): use 'bf16' with mc_dropout")
     mode = {"philox": NOISE_PHILOX, "injected": NOISE_INJECTED, "none": NOISE_NONE}.get(noise)
     if mode is None:
         raise ValueError(f"noise must be 'philox', 'injected' or 'none', got {noise!r}")

@@ -71,12 +71,17 @@ def test_fp32_config2_mean_std_quantiles(golden):
     assert np.all(np.abs(res2.quantiles.cpu().numpy() - g["quantiles"]) <= res2.bin_width.cpu().numpy()[None, :])
 
 
-def test_bf16_config2_within_2e2(golden):
+@pytest.mark.parametrize("dtype", ["bf16", "bf16_fast"])
+def test_bf16_config2_within_2e2(golden, dtype):
+    """Both bf16 precisions against the north star's 2e-2 (measured: exact ELU 2.2e-3 / 2.5e-3, exponent-field ELU
+    4.3e-3 / 3.3e-3 on mean / std; tools/elu_approx_study.py restates both on the CPU)."""
     g = golden("predict_cfg1.npz")
     M, S = int(g["M"]), int(g["S"])
     eps = orc.reference_rng_eps(int(g["eps_seed"]), M, S, 11)
-    res = _run(g, "bf16", S, eps, nbins=128)
+    res = _run(g, dtype, S, eps, nbins=128)
     _check_stats(res, g["mean"], g["std"], 2e-2)
+    if dtype == "bf16_fast":  # the documented accuracy of the exponent-field ELU at this shape
+        _check_stats(res, g["mean"], g["std"], 6e-3)
     width = res.bin_width.cpu().numpy()
     allp = orc.predict_all(torch.from_numpy(g["X"]), torch.from_numpy(g["mu"]), torch.from_numpy(g["rho"]), eps)
     got = res.samples.cpu().numpy()
@@ -161,7 +166,7 @@ def test_ragged_row_counts(golden, B):
     eps = torch.from_numpy(g["eps"])
     M, S = eps.shape[:2]
     allp = orc.predict_all(X, mu, rho, eps)
-    for dtype, tol in (("fp32", 1e-5), ("bf16", 3e-2)):
+    for dtype, tol in (("fp32", 1e-5), ("bf16", 3e-2), ("bf16_fast", 3e-2)):
         res = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype=dtype, noise="injected", eps=eps.reshape(M * S, -1).to(d),
                          return_samples=True)
         assert np.max(np.abs(res.samples.cpu().numpy() - allp.numpy())) <= tol * max(1.0, float(allp.abs().max()))
@@ -306,7 +311,8 @@ def test_ensemble_class_contract(golden):
     assert float(mcd.std.mean()) > float(plain.std.mean())
 
 
-def test_config3_full_size_properties():
+@pytest.mark.parametrize("dtype", ["bf16", "bf16_fast"])
+def test_config3_full_size_properties(dtype):
     """BASELINE configs[2] at full row count (10k series x 365 = 3.65 M rows, 8 members, bf16,
     Philox) with a reduced sample count: size-independent properties + a row subsample against
     the fp32 CPU restatement fed with the CPU restatement of the same Philox counters (2e-2)."""
@@ -324,13 +330,13 @@ def test_config3_full_size_properties():
                 l.bias_mu.add_(0.1 * torch.randn_like(l.bias_mu))
     mu, rho = pack_members(nets, d)
     q = (0.025, 0.5, 0.975)
-    res = mc_predict(X, mu, rho, S, dtype="bf16", noise="philox", seed=seed, q_levels=q, nbins=128)
+    res = mc_predict(X, mu, rho, S, dtype=dtype, noise="philox", seed=seed, q_levels=q, nbins=128)
     assert res.n_samples == M * S
     assert torch.isfinite(res.mean).all() and torch.isfinite(res.std).all() and (res.std > 0).all()
     # quantiles are sorted and bracket the mean's neighbourhood
     assert (res.quantiles[0] <= res.quantiles[1]).all() and (res.quantiles[1] <= res.quantiles[2]).all()
     # chunking (and hence launch shape) must not change the moments: fp64 sums of identical samples
-    res2 = mc_predict(X, mu, rho, S, dtype="bf16", noise="philox", seed=seed, q_levels=q, nbins=128, chunk_pairs=40)
+    res2 = mc_predict(X, mu, rho, S, dtype=dtype, noise="philox", seed=seed, q_levels=q, nbins=128, chunk_pairs=40)
     assert torch.allclose(res2.mean, res.mean, rtol=0, atol=1e-6)
     assert torch.allclose(res2.std, res.std, rtol=1e-6, atol=1e-7)
     # identical rows (same calendar day, same indicators) give identical statistics
@@ -403,15 +409,21 @@ def test_c_abi_rejects_bad_arguments():
     with pytest.raises(ValueError, match="65,535"):
         _lib.check(eng.lib.mcmc_reduce_finalize(eng.ctx.handle, 64, 70000, _p(s), _p(s), _p(Y), _p(Y), _p(Y), 128,
                                                 (__import__("ctypes").c_double * 1)(0.5), 1, _p(Y), _p(Y), _p(Y), _stream()), "x")
+    # the fast bf16 image has no dropout-mask stage
+    with pytest.raises(ValueError, match="MCMC_DT_BF16_FAST"):
+        _lib.check(eng.lib.mcmc_forward_dropout(eng.ctx.handle, 2, _p(Y), 64, 11, _p(Y), 2, 3, 0, 1, 0, 0.1, _p(Y), 64, _stream()), "x")
     # empty inputs are accepted and do nothing
     assert eng.lib.mcmc_forward(eng.ctx.handle, 0, None, 0, 11, None, 0, None, None, None, 1.0, None, 0, _stream()) == 0
 
 
 @pytest.mark.parametrize("F,B", [(1, 33), (12, 100), (15, 64), (16, 97), (17, 200), (24, 513)])
-@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2), ("bf16_fast", 2e-2)])
 def test_input_widths_across_the_k_granule(F, B, dtype, tol):
     """Every input width class: F+1 (bias column) below / at / above the 16-wide bf16 K granule and the
-    kernel's maximum (24), against the oracle's per-pair outputs on the same injected noise."""
+    kernel's maximum (24), against the oracle's per-pair outputs on the same injected noise.
+    The statistics here are over SIX samples, so their relative error is that of single outputs: the exact
+    bf16 path stays within 5e-2, the exponent-field ELU (whose error is about twice as large: 0.03 - 0.07
+    measured, restated on the CPU by tools/elu_approx_study.py) is held to 1e-1."""
     from mcmc_amd import mc_predict
     g = torch.Generator().manual_seed(1000 + F)
     M, S = 2, 3
@@ -431,10 +443,10 @@ def test_input_widths_across_the_k_granule(F, B, dtype, tol):
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.max(np.abs(got - ref)) <= tol * scale, (F, B, dtype, float(np.max(np.abs(got - ref))), scale)
     m_ref, s_ref = orc.reduce_mean_std(torch.from_numpy(ref))
-    _check_stats(res, m_ref.numpy(), s_ref.numpy(), tol if dtype == "fp32" else 5e-2)
+    _check_stats(res, m_ref.numpy(), s_ref.numpy(), {"fp32": tol, "bf16": 5e-2, "bf16_fast": 1e-1}[dtype])
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_fast"])
 def test_predict_plan_graph_replay_equals_eager(golden, dtype):
     """The captured hipGraph of a whole predict gives what mc_predict gives for the same seed, replay after replay."""
     from mcmc_amd import mc_predict

@@ -65,6 +65,8 @@ def test_layout_queries_without_gpu():
         assert lib.mcmc_wpack_bytes(F, _lib.DT_BF16) % 256 == 0
         assert lib.mcmc_wpack_bytes(F, _lib.DT_F32) % 256 == 0
     assert lib.mcmc_wpack_bytes(11, _lib.DT_BF16) == 91392
+    assert lib.mcmc_wpack_bytes(11, _lib.DT_BF16_FAST) == 95232  # + the layer-3 A tile, - the fp32 w3
+    assert lib.mcmc_xpack_bytes(365, 11, _lib.DT_BF16_FAST) == 384 * 16 * 2
     assert lib.mcmc_xpack_bytes(365, 11, _lib.DT_BF16) == 384 * 16 * 2
     assert lib.mcmc_xpack_bytes(365, 11, _lib.DT_F32) == 384 * 12 * 4
     # errors: negative code + message, no exception across the boundary

@@ -24,7 +24,8 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     eng = Engine(dev)
-    dt = _lib.DT_BF16 if args.dtype == "bf16" else _lib.DT_F32
+    from mcmc_amd.engine import resolve_dtype
+    dt = resolve_dtype(args.dtype)
     torch.manual_seed(0)
     X = torch.randn(args.rows, args.F, device=dev)
     M = 8

@@ -1,6 +1,10 @@
-// Dev tool: time forward_bf16_kernel variants (MCMC_ABLATE=0..3, waves) without torch.
-//   hipcc -O3 --offload-arch=gfx950 -DMCMC_ABLATE=1 -Iinclude -Imcmc_amd/csrc tools/fwd_ablate.hip -o build/fwd_ablate1
-#include "../mcmc_amd/csrc/forward_bf16.hip"
+// Dev tool: time the product's forward_bf16_kernel on random operands without torch (ablations: edit a copy of the kernel
+// source and build this harness against it with -DFWD_SRC='"path"').
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Imcmc_amd/csrc tools/fwd_ablate.hip -o build/fwd_ablate
+#ifndef FWD_SRC
+#define FWD_SRC "../mcmc_amd/csrc/forward_bf16.hip"
+#endif
+#include FWD_SRC
 
 #include <stdio.h>
 #include <string.h>
@@ -63,10 +67,6 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double units = (double)rows * pairs;
-#ifndef MCMC_ABLATE
-#define MCMC_ABLATE 0
-#endif
-    printf("ablate=%d waves=%s rows=%lld pairs=%d best %.3f ms  %.1f TFLOP/s(alg)\n", MCMC_ABLATE, getenv("MCMC_FWD_WAVES") ? getenv("MCMC_FWD_WAVES") : "default",
-           (long long)rows, pairs, best, units * 87680.0 / best / 1e9);
+    printf("rows=%lld pairs=%d best %.3f ms  %.1f TFLOP/s(alg)\n", (long long)rows, pairs, best, units * 87680.0 / best / 1e9);
     return 0;
 }
