@@ -134,6 +134,15 @@ int mcmc_reduce_update(mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, 
                        double* sum, double* sumsq, const float* lo, const float* inv_w,
                        uint16_t* hist, int nbins, mcmc_stream_t stream);
 
+/* Sum of n_parts partial states of the SAME rows: the local half of the multi-GPU combine (the reference
+ * combines nothing - it stacks every sample on one device, bayesian_ensemble.py:234-246).  After the
+ * row exchange a rank holds sum_parts / sumsq_parts [n_parts, n_rows] fp64 and hist_parts [n_parts, n_rows, nbins]
+ * uint16 (NULL = no histogram); the sums run in the fixed order p = 0..n_parts-1.  A count above 65,535 saturates and
+ * sets *overflow (device int32, zeroed by the caller; may be NULL) to 1.  All buffers 16-byte aligned. */
+int mcmc_reduce_merge(mcmc_ctx* ctx, int n_parts, int64_t n_rows, const double* sum_parts,
+                      const double* sumsq_parts, const uint16_t* hist_parts, int nbins, double* sum,
+                      double* sumsq, uint16_t* hist, int32_t* overflow, mcmc_stream_t stream);
+
 /* Histogram placement from pilot moments (n0 samples per row already in sum/sumsq): interior
  * bins 1..nbins-2 tile [mean - k*std, mean + k*std), bins 0 and nbins-1 catch the tails. */
 int mcmc_reduce_set_edges(mcmc_ctx* ctx, int64_t n_rows, int64_t n0, const double* sum,

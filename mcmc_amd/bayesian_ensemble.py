@@ -133,7 +133,7 @@ class GPUBayesianEnsemble(nn.Module):
 
     def predict_full(self, X: torch.Tensor, num_samples: int = 100, *, dtype: Optional[str] = None,
                      quantiles: Sequence[float] = (0.025, 0.975), nbins: int = 128, noise: str = "philox",
-                     eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, group=None,
+                     eps: Optional[torch.Tensor] = None, seed: Optional[int] = None, group=False,
                      return_samples: bool = False, chunk_pairs: Optional[int] = None, mc_dropout: bool = False,
                      mask_seed: Optional[int] = None) -> engine.PredictResult:
         """predict() plus the extensions (interval quantiles, injected noise, bf16, sharding, MC dropout:

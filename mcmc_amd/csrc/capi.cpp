@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 13; }
+int mcmc_abi_version(void) { return 14; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -204,6 +204,21 @@ int mcmc_reduce_update(mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, 
         MCMC_REQUIRE((reinterpret_cast<uintptr_t>(hist) & 3u) == 0, "hist must be 4-byte aligned");
     }
     return launch_reduce_update(ctx, Y, ldY, n_pairs, n_rows, sum, sumsq, lo, inv_w, hist, nbins, (hipStream_t)stream);
+}
+
+int mcmc_reduce_merge(mcmc_ctx* ctx, int n_parts, int64_t n_rows, const double* sum_parts, const double* sumsq_parts,
+                      const uint16_t* hist_parts, int nbins, double* sum, double* sumsq, uint16_t* hist, int32_t* overflow,
+                      mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n_parts >= 1 && n_rows >= 0, "n_parts < 1 or n_rows < 0");
+    if (n_rows == 0) return MCMC_OK;
+    MCMC_REQUIRE(sum_parts && sumsq_parts && sum && sumsq, "NULL moments pointer");
+    MCMC_REQUIRE((hist_parts == nullptr) == (hist == nullptr), "hist_parts and hist must both be given or both be NULL");
+    if (hist) {
+        if (int rc = check_nbins(nbins)) return rc;
+        MCMC_REQUIRE(aligned16(hist_parts) && aligned16(hist), "hist_parts and hist must be 16-byte aligned");
+    }
+    return launch_reduce_merge(n_parts, n_rows, sum_parts, sumsq_parts, hist_parts, nbins, sum, sumsq, hist, overflow, (hipStream_t)stream);
 }
 
 int mcmc_reduce_set_edges(mcmc_ctx* ctx, int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins,

@@ -55,6 +55,8 @@ int launch_forward_bf16(const mcmc_ctx* ctx, bool fast, const void* xpack, int64
                         const DropMask* dm, float* Y, int64_t ldY, hipStream_t s);
 int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
                          double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s);
+int launch_reduce_merge(int n_parts, int64_t n_rows, const double* sum_parts, const double* sumsq_parts, const uint16_t* hist_parts,
+                        int nbins, double* sum, double* sumsq, uint16_t* hist, int* overflow, hipStream_t s);
 int launch_set_edges(int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins, float range_sigmas,
                      float* lo, float* inv_w, hipStream_t s);
 int launch_finalize(int64_t n_rows, int64_t n, const double* sum, const double* sumsq, const uint16_t* hist,

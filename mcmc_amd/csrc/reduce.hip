@@ -11,8 +11,6 @@
 //   packed uint16 pairs (row-rotated so rows falling in the same bin hit different banks), and
 //   are added to the global uint16 histogram once per chunk - the tile owns its rows, so global
 //   state is updated without atomics and the result is bitwise deterministic.
-#include <stdlib.h>
-
 #include <type_traits>
 
 #include "common.hpp"
@@ -150,9 +148,6 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
     }
 
     double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 2)
-    float f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
-#endif
     const f32x4* yp = reinterpret_cast<const f32x4*>(Y + row0);
     const int64_t ld4 = ldY >> 2;
     // Histogram address arithmetic, 9 VALU instructions per sample: with u = bin + 4*rq (the row
@@ -164,14 +159,9 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
         const float v[4] = {q[0], q[1], q[2], q[3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 2)
-            f1[j] += v[j];
-            f2[j] = fmaf(v[j], v[j], f2[j]);
-#else
             const double d = (double)v[j];
             s1[j] += d;
             s2[j] = fma(d, d, s2[j]);
-#endif
             if (HIST && (!decltype(tail)::value || row0 + j < n_rows)) {
                 // same arithmetic as hist_bin(): two roundings, clamp to [-1, nbins-2] (NaN -> -1), floor
                 const float t = __builtin_amdgcn_fmed3f(__fmul_rn(__fsub_rn(v[j], lo[j]), inv_w[j]), -1.0f, hi_clamp);
@@ -179,13 +169,7 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
                 asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(bm1) : "v"(t));
                 const unsigned u = (unsigned)(bm1 + 1 + 4 * rq);
                 const unsigned word = __builtin_amdgcn_ubfe(u, 1, lw);
-#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 1)
-                uint32_t* ap = &lh[(4 * rq + j) * words + word];
-                const unsigned av = (u & 1u) * 65535u + 1u;
-                asm volatile("" ::"v"(ap), "v"(av));
-#else
                 atomicAdd(&lh[(4 * rq + j) * words + word], (u & 1u) * 65535u + 1u);
-#endif
             }
         }
     };
@@ -210,9 +194,6 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
             for (int c = slot; c < n_pairs; c += kSlots) consume(__builtin_nontemporal_load(yp + (int64_t)c * ld4), yes{});
         }
     }
-#if defined(MCMC_RED_ABL) && (MCMC_RED_ABL & 2)
-    for (int j = 0; j < 4; ++j) { s1[j] = f1[j]; s2[j] = f2[j]; }
-#endif
     // the 4 pair-slots of a wave sit 16 lanes apart: fold them, then the waves through LDS
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -278,6 +259,51 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
             }
         }
     }
+}
+
+// ---- merge of partial states (the local half of the multi-GPU reduce-scatter) ----
+// parts[p] are W partial states of the SAME rows, one per rank, as they arrive from the row exchange; the sum runs
+// in the fixed order p = 0..W-1 (deterministic, the same on every rank for its rows).
+__global__ __launch_bounds__(256) void merge_moments_kernel(int n_parts, int64_t n, const double* __restrict__ parts_a,
+                                                            const double* __restrict__ parts_b, double* __restrict__ out_a,
+                                                            double* __restrict__ out_b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (int p = 0; p < n_parts; ++p) {
+            a += parts_a[(int64_t)p * n + i];
+            b += parts_b[(int64_t)p * n + i];
+        }
+        out_a[i] = a;
+        out_b[i] = b;
+    }
+}
+
+// uint16 counts, two per 32-bit word, four words per thread step; the halves are summed apart in 32 bits, so a
+// total above 65,535 is seen (flag raised, count saturated) instead of carrying into its neighbour
+typedef uint32_t u32x4m __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void merge_hist_kernel(int n_parts, int64_t n_vec, const u32x4m* __restrict__ parts,
+                                                         u32x4m* __restrict__ out, int* __restrict__ overflow) {
+    bool over = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
+        for (int p = 0; p < n_parts; ++p) {
+            const u32x4m w = __builtin_nontemporal_load(parts + (int64_t)p * n_vec + i);
+            const uint32_t v[4] = {w[0], w[1], w[2], w[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lo[j] += v[j] & 0xFFFFu;
+                hi[j] += v[j] >> 16;
+            }
+        }
+        uint32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            over |= lo[j] > 0xFFFFu || hi[j] > 0xFFFFu;
+            r[j] = (lo[j] > 0xFFFFu ? 0xFFFFu : lo[j]) | ((hi[j] > 0xFFFFu ? 0xFFFFu : hi[j]) << 16);
+        }
+        out[i] = u32x4m{r[0], r[1], r[2], r[3]};
+    }
+    if (over && overflow) *overflow = 1;  // plain vector store of the same value from every lane that saw one
 }
 
 __global__ __launch_bounds__(256) void set_edges_kernel(int64_t n_rows, double n0, const double* __restrict__ sum,
@@ -382,8 +408,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n_rows, double n,
 int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n_pairs, int64_t n_rows, double* sum,
                          double* sumsq, const float* lo, const float* inv_w, uint16_t* hist, int nbins, hipStream_t s) {
     (void)ctx;
-    static const bool force4b = getenv("MCMC_REDUCE_4B") != nullptr;  // dev knob: the 4-byte-per-lane kernel
-    const bool wide = !force4b && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0 && (ldY & 3) == 0;
+    const bool wide = (reinterpret_cast<uintptr_t>(Y) & 15u) == 0 && (ldY & 3) == 0;  // else: the 4-byte-per-lane kernel
     if (wide) {
         const int64_t blocks = (n_rows + kRows - 1) / kRows;
         const size_t red_bytes = 2 * kWavesR * kRows * sizeof(double);
@@ -414,6 +439,21 @@ int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n
                            n_pairs, n_rows, sum, sumsq, nullptr, nullptr, nullptr, 0);
     }
     return check_launch("reduce_update");
+}
+
+int launch_reduce_merge(int n_parts, int64_t n_rows, const double* sum_parts, const double* sumsq_parts, const uint16_t* hist_parts,
+                        int nbins, double* sum, double* sumsq, uint16_t* hist, int* overflow, hipStream_t s) {
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(merge_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_parts, n_rows, sum_parts, sumsq_parts, sum, sumsq);
+    if (hist) {
+        const int64_t n_vec = n_rows * nbins / 8;  // nbins is a multiple of 64: whole uint4s per row
+        blocks = (n_vec + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(merge_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, n_parts, n_vec, reinterpret_cast<const u32x4m*>(hist_parts),
+                           reinterpret_cast<u32x4m*>(hist), overflow);
+    }
+    return check_launch("reduce_merge");
 }
 
 int launch_set_edges(int64_t n_rows, int64_t n0, const double* sum, const double* sumsq, int nbins, float range_sigmas,

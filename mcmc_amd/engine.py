@@ -101,7 +101,7 @@ def _single_process(group) -> bool:
     MCMC_FORCE_COLLECTIVES=1 (test aid) sends a one-rank group through the collectives anyway, so a one-GPU box
     can exercise the RCCL calls (dtypes, split sizes) of the multi-rank path."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
+    if group is False or not (dist.is_available() and dist.is_initialized()):
         return True
     return dist.get_world_size(group) == 1 and os.environ.get("MCMC_FORCE_COLLECTIVES") != "1"
 
@@ -151,17 +151,22 @@ def row_slice(B: int, rank: int, world: int) -> Tuple[int, int, int]:
     return min(rank * per, B), min((rank + 1) * per, B), per
 
 
-def scatter_combine(state: ReduceState, group=None) -> Tuple[ReduceState, int, int]:
+def scatter_combine(state: ReduceState, group=None, merge=None) -> Tuple[ReduceState, int, int]:
     """Reduce-scatter over rows: every rank ends up with the fully combined partials
-    of its own row slice only.  Built on all_to_all_single + a local sum (the same wire traffic as
-    a reduce-scatter, (W-1)/W of the payload per rank, and available on RCCL and gloo alike), so the
+    of its own row slice only.  Built on all_to_all_single of raw bytes + ``merge`` (Engine.reduce_merge =
+    mcmc_reduce_merge: the sum of the world's slices in rank order, in the library): the same wire traffic as
+    a reduce-scatter, (W-1)/W of the payload per rank, available on RCCL and gloo alike, so the
     ~B*nbins*2-byte histogram crosses xGMI once instead of twice as in an all-reduce.
     Returns (state of the slice, row_begin, row_end); lo / inv_w are sliced locally (identical on
-    all ranks by construction: they come from the all-reduced pilot)."""
+    all ranks by construction: they come from the all-reduced pilot).
+    ``merge(sum_parts [W,rows] f64, sumsq_parts, hist_parts [W,rows,nbins] int16 | None, nbins) -> (sum, sumsq, hist)``;
+    the CPU tests of the exchange logic pass a numpy stand-in, the product always the HIP kernel."""
     import torch.distributed as dist
     B = state.sum.shape[0]
     if _single_process(group):
         return state, 0, B
+    if merge is None:
+        raise RuntimeError("scatter_combine needs the library's merge (Engine.reduce_merge); mcmc_amd has no CPU path")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bounds = [row_slice(B, r, world)[:2] for r in range(world)]
     r0, r1 = bounds[rank]
@@ -183,11 +188,12 @@ def scatter_combine(state: ReduceState, group=None) -> Tuple[ReduceState, int, i
     count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
     all_reduce_sum(count, group)
     n = int(count.item())
-    out = ReduceState(n, exchange(state.sum).sum(0), exchange(state.sumsq).sum(0), nbins=state.nbins)
+    if state.hist is not None and n > 65535:
+        raise ValueError(f"uint16 histogram holds at most 65,535 samples per row (n = {n})")
+    s1, s2, hist = merge(exchange(state.sum), exchange(state.sumsq), exchange(state.hist) if state.hist is not None else None, state.nbins)
+    out = ReduceState(n, s1, s2, nbins=state.nbins)
     if state.hist is not None:
-        if n > 65535:
-            raise ValueError(f"uint16 histogram holds at most 65,535 samples per row (n = {n})")
-        out.hist = exchange(state.hist).sum(0, dtype=torch.int16)  # wraps like uint16: totals stay <= 65,535
+        out.hist = hist
         out.lo, out.inv_w = state.lo[r0:r1].contiguous(), state.inv_w[r0:r1].contiguous()
     return out, r0, r1
 
@@ -202,7 +208,8 @@ def gather_rows(parts: Sequence[Optional[torch.Tensor]], B: int, group=None) -> 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     r0, r1, per = row_slice(B, rank, world)
     present = [t for t in parts if t is not None]
-    blocks = [t.reshape(-1, r1 - r0).to(torch.float32) for t in present]
+    # the row count of each part comes from its rank, not from reshape(-1, rows): an empty slice (B < world) packs as [k, 0]
+    blocks = [(t.reshape(1, r1 - r0) if t.dim() == 1 else t).to(torch.float32) for t in present]
     K = sum(b.shape[0] for b in blocks)
     packed = torch.zeros(K, per, dtype=torch.float32, device=present[0].device)
     if r1 > r0:
@@ -300,6 +307,20 @@ class Engine:
                    "mcmc_reduce_update")
         st.n += n_pairs
 
+    def reduce_merge(self, sum_parts: torch.Tensor, sumsq_parts: torch.Tensor, hist_parts: Optional[torch.Tensor], nbins: int):
+        """Sum of the W partial states of one row slice, in rank order (mcmc_reduce_merge)."""
+        W, rows = sum_parts.shape
+        s1 = torch.empty(rows, dtype=torch.float64, device=self.device)
+        s2 = torch.empty(rows, dtype=torch.float64, device=self.device)
+        hist = torch.empty(rows, nbins, dtype=torch.int16, device=self.device) if hist_parts is not None else None
+        over = torch.zeros(1, dtype=torch.int32, device=self.device) if hist_parts is not None else None
+        _lib.check(self.lib.mcmc_reduce_merge(self.ctx.handle, W, rows, _p(sum_parts.contiguous()), _p(sumsq_parts.contiguous()),
+                                              _p(hist_parts.contiguous() if hist_parts is not None else None), nbins, _p(s1), _p(s2),
+                                              _p(hist), _p(over), _stream()), "mcmc_reduce_merge")
+        if over is not None and int(over.item()):
+            raise ValueError("a histogram count exceeded 65,535 in the combine (uint16 counts)")
+        return s1, s2, hist
+
     def set_edges(self, B: int, n0: int, psum, psumsq, st: ReduceState, range_sigmas: float):
         _lib.check(self.lib.mcmc_reduce_set_edges(self.ctx.handle, B, n0, _p(psum), _p(psumsq), st.nbins, range_sigmas,
                                                   _p(st.lo), _p(st.inv_w), _stream()), "mcmc_reduce_set_edges")
@@ -349,9 +370,11 @@ PILOT_PAIRS = 128
 
 
 def pilot_pairs(cnt: int, M: int) -> int:
-    """Pairs of the first chunk whose moments place the histogram (whole rounds of members, ~128 per rank):
-    the range is mean +- range_sigmas * std with catch-all end bins, so a 6 % error of the pilot's std moves
-    the edges by a fraction of a sigma; reducing the whole first chunk twice would cost a full extra pass."""
+    """Pairs whose moments place the histogram: the first ~128 in processing order (whole rounds of members),
+    q = 0 .. pilot_pairs-1 whichever rank owns them, so the bin edges - and with them the quantiles - do not
+    depend on the world size.  The range is mean +- range_sigmas * std with catch-all end bins, so a 6 % error
+    of the pilot's std moves the edges by a fraction of a sigma; reducing a whole chunk twice would cost a full
+    extra pass."""
     want = max(M, PILOT_PAIRS // M * M)
     return min(cnt, want)
 
@@ -372,7 +395,7 @@ def default_chunk_pairs(ldY: int, wpack_bytes: int, M: int, device) -> int:
 def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples: int, *, dtype="fp32",
                noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
                q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
-               chunk_pairs: Optional[int] = None, group=None, return_samples: bool = False,
+               chunk_pairs: Optional[int] = None, group=False, return_samples: bool = False,
                timers: Optional[dict] = None, mc_dropout: bool = False, p_drop: float = 0.1,
                mask_seed: Optional[int] = None) -> PredictResult:
     """Monte Carlo predictive statistics of the ensemble over X.
@@ -381,9 +404,11 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     (bf16 MFMA operands, exact ELU) or 'bf16_fast' (bf16 operands, exponent-field ELU: include/mcmc_hip.h).  noise: 'philox'
     (counter-based, keyed by seed and the global pair id: independent of chunking and world
     size), 'injected' (eps [M*S,P] fp32 in the reference's draw order) or 'none' (sample=False).
-    With torch.distributed initialised (backend 'nccl' = RCCL), the M*S pairs are sharded over
-    the ranks of ``group``; the partial (sum, sumsq, histogram) are reduce-scattered over rows, each
-    rank finalizes its row slice, and the results are all-gathered: every rank returns the full
+    ``group=False`` (default): this process computes all M*S pairs, as the reference does - also under
+    torch.distributed, where ranks may be predicting different inputs.  ``group=None`` (the default process
+    group; backend 'nccl' = RCCL) or a group: the M*S pairs are sharded over its ranks - every rank must
+    call with the same X, mu, rho and seed; the partial (sum, sumsq, histogram) are reduce-scattered over
+    rows, each rank finalizes its row slice, and the results are all-gathered: every rank returns the full
     result.  ``timers``: optional dict; per kernel name it collects
     (start, end) torch.cuda.Event pairs recorded on the launch stream around each launch.
     ``mc_dropout`` (extension; the reference's predict() runs in eval mode, bayesian_ensemble.py:215-216):
@@ -419,7 +444,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     if nq and N > 65535:
         raise ValueError(f"quantile histograms count in uint16: M*S = {N} exceeds 65,535")
 
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    sharded = group is not False and dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if sharded else 1
     rank = dist.get_rank(group) if world > 1 else 0
     q_begin, q_end = shard_pairs(N, rank, world)
     n_local = q_end - q_begin
@@ -428,8 +454,9 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
         xpack = eng.pack_x(X, dt)
         ldY = (B + 63) // 64 * 64
         wbytes = eng.wpack_bytes(F, dt)
-        Cn = chunk_pairs or default_chunk_pairs(ldY, wbytes, M, eng.device)
-        Cn = max(1, min(Cn, max(n_local, 1)))
+        cap = chunk_pairs or default_chunk_pairs(ldY, wbytes, M, eng.device)
+        Cn = max(1, min(cap, max(n_local, 1)))
+        n_pilot = min(pilot_pairs(N, M), cap)  # in every owner's first chunk, whatever the world size
         Y = torch.empty(Cn, ldY, dtype=torch.float32, device=eng.device)
         wpack = torch.empty(Cn * wbytes, dtype=torch.uint8, device=eng.device)
         st = eng.new_state(B, nbins if nq else 0)
@@ -446,11 +473,16 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                 eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY,
                             philox_dropout=(seed if mask_seed is None else mask_seed, p_drop, M, S, begin) if mc_dropout else None)
             if nq and first:
-                # pilot: the first chunk's moments (all ranks') place every row's histogram
-                pilot = eng.new_state(B)
-                eng.reduce_update(Y, ldY, pilot_pairs(cnt, M), B, pilot)
-                pilot = combine_partials(pilot, group)
-                eng.set_edges(B, pilot.n, pilot.sum, pilot.sumsq, st, range_sigmas)
+                # pilot: the moments of global pairs q < n_pilot place every row's histogram.  They sit at the head of
+                # the ranks that own them (rank 0 alone when its shard has >= n_pilot pairs) and in their first chunk
+                # as long as chunk_pairs >= n_pilot; every rank joins the sum, so all ranks bin identically.
+                with _timed(timers, "pilot"):
+                    pilot = eng.new_state(B)
+                    mine = max(0, min(cnt, n_pilot - begin))
+                    if mine:
+                        eng.reduce_update(Y, ldY, mine, B, pilot)
+                    pilot = combine_partials(pilot, group)
+                    eng.set_edges(B, max(pilot.n, 1), pilot.sum, pilot.sumsq, st, range_sigmas)
             first = False
             with _timed(timers, "reduce_update", cnt):
                 eng.reduce_update(Y, ldY, cnt, B, st)
@@ -462,9 +494,12 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
 
         width = (1.0 / st.inv_w) if nq else None
         # exchange step: reduce-scatter over rows -> finalize the own slice -> all-gather the results
-        part, r0, r1 = scatter_combine(st, group)
-        mean, std, quant = eng.finalize(r1 - r0, part, q_levels)
-        mean, std, quant = gather_rows([mean, std, quant], B, group)
+        with _timed(timers, "exchange"):
+            part, r0, r1 = scatter_combine(st, group, eng.reduce_merge)
+        with _timed(timers, "finalize"):
+            mean, std, quant = eng.finalize(r1 - r0, part, q_levels)
+        with _timed(timers, "gather"):
+            mean, std, quant = gather_rows([mean, std, quant], B, group)
     return PredictResult(mean, std, quant, width, samples, part.n)
 
 

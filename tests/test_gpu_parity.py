@@ -533,3 +533,45 @@ def test_bf16_host_masks_equal_philox_masks(golden):
     eng.forward(_lib.DT_BF16, xp, B, F, wp, npass, Y, ldY, masks=masks, keep_scale=float(torch.tensor(1.0 / 0.9, dtype=torch.float32)))
     got = Y[:, :B].cpu().numpy()
     assert np.max(np.abs(got - g["out"])) <= 2e-2 * max(1.0, np.max(np.abs(g["out"])))
+
+
+@pytest.mark.parametrize("W,rows,nbins", [(8, 457, 128), (2, 64, 64), (3, 1, 512)])
+def test_reduce_merge_bit_exact(W, rows, nbins):
+    """mcmc_reduce_merge (the local half of the multi-GPU reduce-scatter) against numpy: fp64 sums in rank order bit for
+    bit, uint16 counts exact; a count that passes 65,535 saturates and raises instead of carrying into its neighbour."""
+    from mcmc_amd.engine import Engine
+    rng = np.random.default_rng(W * 1000 + rows)
+    eng = Engine(_dev())
+    s1 = rng.normal(size=(W, rows)) * 1e3
+    s2 = rng.random(size=(W, rows)) * 1e6
+    hist = rng.integers(0, 65535 // W + 1, size=(W, rows, nbins)).astype(np.uint16)
+    hist[:, 0, 0] = 65535 // W  # the largest legal total
+    d = _dev()
+    a, b, h = eng.reduce_merge(torch.from_numpy(s1).to(d), torch.from_numpy(s2).to(d), torch.from_numpy(hist.view(np.int16)).to(d), nbins)
+    ra, rb = s1[0].copy(), s2[0].copy()
+    for p in range(1, W):
+        ra += s1[p]
+        rb += s2[p]
+    assert np.array_equal(a.cpu().numpy(), ra) and np.array_equal(b.cpu().numpy(), rb)
+    assert np.array_equal(h.cpu().numpy().view(np.uint16).astype(np.int64), hist.astype(np.int64).sum(0))
+    a2, b2, none = eng.reduce_merge(torch.from_numpy(s1).to(d), torch.from_numpy(s2).to(d), None, 0)
+    assert none is None and np.array_equal(a2.cpu().numpy(), ra)
+    if W > 1:
+        hist[:, rows - 1, nbins - 1] = 40000
+        with pytest.raises(ValueError, match="65,535"):
+            eng.reduce_merge(torch.from_numpy(s1).to(d), torch.from_numpy(s2).to(d), torch.from_numpy(hist.view(np.int16)).to(d), nbins)
+
+
+def test_device_generator_equals_cpu():
+    """Row f3: the batched generator draws from Philox in integer torch ops, so a HIP device and the CPU give the same
+    series for a seed: identical promotion / weather indicator columns, X and y equal to float rounding."""
+    from mcmc_amd.data import make_series_batch
+    Xc, yc = make_series_batch(300, seed=77, standardize=False)
+    Xg, yg = make_series_batch(300, seed=77, standardize=False, device=_dev())
+    assert torch.equal(Xg.cpu()[:, :5], Xc[:, :5])          # indicator columns: integer draws only
+    assert torch.allclose(Xg.cpu()[:, 5:], Xc[:, 5:], rtol=0, atol=1e-6)   # calendar columns
+    assert torch.allclose(yg.cpu(), yc, rtol=1e-5, atol=1e-3)
+    Xc, yc = make_series_batch(300, seed=77)
+    Xg, yg = make_series_batch(300, seed=77, device=_dev())
+    assert torch.allclose(Xg.cpu(), Xc, rtol=0, atol=2e-6)
+    assert torch.allclose(yg.cpu(), yc, rtol=0, atol=1e-4), float((yg.cpu() - yc).abs().max())  # fp32 sums on two devices

@@ -178,24 +178,41 @@ def test_pair_order_is_a_member_interleaved_permutation():
     assert g[:6].tolist() == [0, 100, 200, 300, 400, 1]
 
 
-# --------------------------------------------------------------------------- world_size-2 combine over gloo
-def _combine_worker(rank, world, port, tmp):
+# --------------------------------------------------------------------------- multi-rank combine over gloo (world 2 .. 8)
+def _numpy_merge(sum_parts, sumsq_parts, hist_parts, nbins):
+    """Test stand-in for Engine.reduce_merge (mcmc_reduce_merge, checked bit for bit against this rule on the GPU in
+    tests/test_gpu_parity.py::test_reduce_merge_bit_exact): rank-order sums, uint16 counts."""
+    s1, s2 = sum_parts[0].clone(), sumsq_parts[0].clone()
+    for p in range(1, sum_parts.shape[0]):
+        s1 += sum_parts[p]
+        s2 += sumsq_parts[p]
+    hist = None
+    if hist_parts is not None:
+        tot = hist_parts.numpy().view(np.uint16).astype(np.int64).sum(0)
+        assert tot.max(initial=0) <= 65535
+        hist = torch.from_numpy(tot.astype(np.uint16).view(np.int16))
+    return s1, s2, hist
+
+
+def _combine_worker(rank, world, port, tmp, N, B):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from mcmc_amd.engine import ReduceState, combine_partials, gather_rows, row_slice, scatter_combine, shard_pairs
         rng = np.random.default_rng(0)
-        N, B, nbins = 64, 33, 128
-        Y = (rng.normal(size=(N, B)) * 1.5 + rng.normal(size=B)).astype(np.float32)  # all "samples", same on both ranks
+        nbins, n_pilot = 128, min(16, N)
+        Y = (rng.normal(size=(N, B)) * 1.5 + rng.normal(size=B)).astype(np.float32)  # all "samples", same on every rank
         b, e = shard_pairs(N, rank, world)
-        # pilot = each rank's first 8 samples, combined
-        pil = Y[b:b + 8].astype(np.float64)
-        pilot = ReduceState(8, torch.from_numpy(pil.sum(0)), torch.from_numpy((pil ** 2).sum(0)))
+        # pilot = global pairs q < n_pilot, whichever ranks own them (mc_predict's rule), combined
+        pil = Y[b:max(b, min(e, n_pilot))].astype(np.float64)
+        pilot = ReduceState(pil.shape[0], torch.from_numpy(pil.sum(0)), torch.from_numpy((pil ** 2).sum(0)))
         pilot = combine_partials(pilot)
-        assert pilot.n == 8 * world
+        assert pilot.n == n_pilot
+        ref_pil = Y[:n_pilot].astype(np.float64)
+        assert np.allclose(pilot.sum.numpy(), ref_pil.sum(0), rtol=1e-14)
         lo, inv_w = orc.hist_edges_from_pilot(pilot.n, pilot.sum.numpy(), pilot.sumsq.numpy(), nbins, 6.0)
-        mine = Y[b:e]
+        mine = Y[b:e]  # empty on ranks beyond the pair count
         hist = orc.hist_accumulate(mine, lo, inv_w, nbins).astype(np.uint16).view(np.int16)
         st = ReduceState(e - b, torch.from_numpy(mine.astype(np.float64).sum(0)),
                          torch.from_numpy((mine.astype(np.float64) ** 2).sum(0)), torch.from_numpy(hist.copy()),
@@ -210,35 +227,47 @@ def _combine_worker(rank, world, port, tmp):
         tm, ts = orc.reduce_mean_std(torch.from_numpy(Y))
         assert np.allclose(mean, tm.numpy(), atol=1e-6) and np.allclose(std, ts.numpy(), rtol=1e-5)
         tq = torch.quantile(torch.from_numpy(Y), torch.tensor([0.025, 0.975]), dim=0).numpy()
-        assert np.all(np.abs(q - tq) <= 1.0 / inv_w[None, :])
+        if N >= 32:  # with a handful of samples the pilot's sigma is too rough for the one-bin guarantee
+            assert np.all(np.abs(q - tq) <= 1.0 / inv_w[None, :])
         # the product's exchange: reduce-scatter over rows -> finalize own slice -> all-gather
-        part, r0, r1 = scatter_combine(part0)
+        part, r0, r1 = scatter_combine(part0, None, _numpy_merge)
         assert (r0, r1) == row_slice(B, rank, world)[:2] and part.n == N and part.sum.shape[0] == r1 - r0
         # fp64 sums: same addends, possibly another association than the all-reduce's
         assert torch.allclose(part.sum, st.sum[r0:r1], rtol=1e-14, atol=0) and torch.allclose(part.sumsq, st.sumsq[r0:r1], rtol=1e-14, atol=0)
         assert torch.equal(part.hist, st.hist[r0:r1]) and part.hist.dtype == torch.int16
-        pm, ps, pq = orc.finalize_from_state(part.n, part.sum.numpy(), part.sumsq.numpy(),
-                                             part.hist.numpy().view(np.uint16).astype(np.int64), part.lo.numpy(), part.inv_w.numpy(),
-                                             (0.025, 0.975))
+        if r1 > r0:
+            pm, ps, pq = orc.finalize_from_state(part.n, part.sum.numpy(), part.sumsq.numpy(),
+                                                 part.hist.numpy().view(np.uint16).astype(np.int64), part.lo.numpy(), part.inv_w.numpy(),
+                                                 (0.025, 0.975))
+        else:  # B < world: this rank finalizes no rows and still joins the gather
+            pm, ps, pq = np.zeros(0), np.zeros(0), np.zeros((2, 0))
         gm, gs, gq, none = gather_rows([torch.from_numpy(np.asarray(pm, dtype=np.float32)), torch.from_numpy(np.asarray(ps, dtype=np.float32)),
                                         torch.from_numpy(np.asarray(pq, dtype=np.float32)), None], B)
         assert none is None and gm.shape == (B,) and gq.shape == (2, B)
         assert np.allclose(gm.numpy(), mean, rtol=1e-6, atol=1e-7) and np.allclose(gs.numpy(), std, rtol=1e-6)
         assert np.array_equal(gq.numpy(), np.asarray(q, dtype=np.float32))   # histogram counts are exact
+        # without the library's merge there is no combine: no CPU path
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            scatter_combine(part0)
+        # group=False: single-process semantics under an initialised process group
+        same, a0, a1 = scatter_combine(part0, False)
+        assert same is part0 and (a0, a1) == (0, B)
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_combine_partials_gloo(tmp_path, world):
+# (world, pairs, rows): even and ragged row slices, B not divisible by 8, fewer pairs than ranks (idle ranks still join every
+# collective), fewer rows than ranks (empty row slices)
+@pytest.mark.parametrize("world,N,B", [(2, 64, 33), (3, 64, 33), (8, 64, 33), (8, 5, 70), (8, 64, 9), (3, 16, 1), (3, 16, 2)])
+def test_combine_partials_gloo(tmp_path, world, N, B):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_combine_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_combine_worker, args=(world, port, str(tmp_path), N, B), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 
@@ -249,6 +278,19 @@ def test_combine_is_identity_without_process_group():
 
 
 # --------------------------------------------------------------------------- generator (row f3)
+def test_generator_philox_matches_oracle():
+    """The generator's Philox (integer torch ops) against the oracle's, which the published known-answer vectors pin."""
+    from mcmc_amd.data import philox_u32
+    seed, stream, n = 0xFEDCBA9876543210, 5, 1003
+    got = philox_u32(seed, stream, n, "cpu").numpy().astype(np.uint32)
+    ctr = np.zeros(((n + 3) // 4, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(ctr.shape[0])
+    ctr[:, 1] = stream
+    key = np.array([seed & 0xFFFFFFFF, seed >> 32], dtype=np.uint32)
+    ref = orc.philox4x32_10(ctr, np.broadcast_to(key, (ctr.shape[0], 2))).reshape(-1)[:n]
+    assert np.array_equal(got, ref)
+
+
 def test_series_batch_generator():
     from mcmc_amd.data import calendar_features, make_series_batch
     X, y = make_series_batch(50, seed=4, standardize=False)
