@@ -184,7 +184,7 @@ int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n,
  *                             the gradient w.r.t. the effective weights of every pair
  *   xb [M,rows,F], yb [M,rows] : each member's mini-batch (DataLoader order differs per member)
  *   Y [M*S,rows], delta [M,rows], loss [M]
- * mask_mode: 0 none, 1 host uint8 keep-masks [M*S,rows,256/128/64], 2 Philox keyed
+ * mask_mode: 0 none, 1 host uint8 keep-masks [M*S,rows,256/128/64] (4-byte aligned), 2 Philox keyed
  * (mask_seed; pair, row, element) with keep probability 1-p_drop (bayesian_ensemble.py:71,86). */
 int mcmc_train_sigma(mcmc_ctx* ctx, const float* rho, float* sigma, int64_t n, mcmc_stream_t stream);
 /* eps (injected copy or Philox), W = mu + eps*sigma in both layouts (bayesian_ensemble.py:43-44). */

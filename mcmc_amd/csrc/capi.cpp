@@ -295,6 +295,8 @@ static int check_train(int n_members, int n_samples, int input_dim, int64_t rows
 static int check_masks(int mask_mode, const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, float p_drop) {
     MCMC_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "mask_mode must be 0 (none), 1 (host) or 2 (philox)");
     MCMC_REQUIRE(mask_mode != 1 || (m0 && m1 && m2), "mask_mode 1 needs mask0, mask1 and mask2");
+    MCMC_REQUIRE(mask_mode != 1 || ((reinterpret_cast<uintptr_t>(m0) | reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2)) & 3u) == 0,
+                 "host keep-masks must be 4-byte aligned (the kernels read four flags per load)");
     MCMC_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "p_drop must be in [0, 1)");
     return MCMC_OK;
 }

@@ -57,6 +57,29 @@ def pack_members(models: Sequence[torch.nn.Module], device) -> Tuple[torch.Tenso
     return mu, rho
 
 
+def device_guarded(cls):
+    """Class decorator: every method of a class that owns an ``eng`` (Engine) runs with that engine's device current.
+    The C ABI rejects a context whose device is not the current one and takes the stream of the current device, so an
+    object built for cuda:1 must work while cuda:0 is current (main.py:236-238 assigns task i to device i % n)."""
+    import functools
+
+    def guard(fn):
+        @functools.wraps(fn)
+        def wrapped(self, *args, **kw):
+            eng = getattr(self, "eng", None)
+            dev = eng.device if eng is not None else next((a.device for a in args if isinstance(a, torch.Tensor)), None)
+            if dev is None or dev.type != "cuda":
+                return fn(self, *args, **kw)  # Engine() names the missing HIP device
+            with torch.cuda.device(dev):
+                return fn(self, *args, **kw)
+        return wrapped
+
+    for name, fn in list(vars(cls).items()):
+        if callable(fn) and not isinstance(fn, (staticmethod, classmethod, type)) and (name == "__init__" or not name.startswith("__")):
+            setattr(cls, name, guard(fn))
+    return cls
+
+
 def _require_gpu(t: torch.Tensor, what: str) -> int:
     if not t.is_cuda:
         raise RuntimeError(f"{what} must live on a HIP device (got {t.device}); mcmc_amd has no CPU path")

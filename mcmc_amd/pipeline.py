@@ -135,6 +135,8 @@ def process_bayesian_task(features: torch.Tensor, temporal: torch.Tensor, target
     ensemble and, with ``include_tft``, the TFT.  Returns (combo_name, {"bayesian": record[, "tft": record]})."""
     from .bayesian_ensemble import GPUBayesianEnsemble
     device = torch.device(device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)  # main.py:66-67
     name = combo_name(combo)
     log(f"Training models for combination: {name} on {device}")
     X = select_features(features, temporal, combo).rename(None).to(device)

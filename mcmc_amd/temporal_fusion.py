@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import Engine, _p, _stream
+from .engine import Engine, _p, _stream, device_guarded
 from .train import one_cycle_schedule
 
 HIDDEN, HEADS = 64, 4
@@ -80,6 +80,7 @@ class TemporalFusionTransformer(nn.Module):
         raise NotImplementedError("use TFTModel.predict / TFTEngine.forward: the HIP path evaluates the last timestep of each window")
 
 
+@device_guarded
 class TFTEngine:
     """Device state of one TFT: flat parameters, AdamW moments, work buffers; typed calls into the C ABI."""
 

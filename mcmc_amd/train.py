@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 from ._lib import NOISE_INJECTED, NOISE_NONE, NOISE_PHILOX, TrainBuffers, TrainHyper
-from .engine import HIDDEN, Engine, _p, _stream, all_reduce_sum, param_count
+from .engine import HIDDEN, Engine, _p, _stream, all_reduce_sum, device_guarded, param_count
 
 MASK_NONE, MASK_HOST, MASK_PHILOX = 0, 1, 2
 _GOLDEN = 0x9E3779B97F4A7C15
@@ -39,6 +39,7 @@ def _dp_world(group) -> int:
     return dist.get_world_size(group)
 
 
+@device_guarded
 class EnsembleTrainer:
     """Device state of M members trained in lock-step: parameters, AdamW moments, work buffers.
 
@@ -321,7 +322,13 @@ def one_cycle_schedule(epochs: int, steps_per_epoch: int) -> Tuple[List[float], 
     return list(lrs), list(b1s)
 
 
-def fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epochs: int = 400, batch_size: int = 32, *,
+def fit_ensemble(trainer: EnsembleTrainer, *args, **kw):
+    """``_fit_ensemble`` with the trainer's device current (its early-stop kernel and streams need it)."""
+    with torch.cuda.device(trainer.eng.device):
+        return _fit_ensemble(trainer, *args, **kw)
+
+
+def _fit_ensemble(trainer: EnsembleTrainer, X: torch.Tensor, y: torch.Tensor, epochs: int = 400, batch_size: int = 32, *,
                  seed: int = 0, patience: int = 25, log=print, generator: Optional[torch.Generator] = None, lookahead: int = 8):
     """The reference's training loop (bayesian_ensemble.py:152-200) for all members at once.
 

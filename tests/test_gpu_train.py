@@ -339,3 +339,19 @@ def test_pipeline_bayesian_task_end_to_end(golden, tmp_path):
         assert sum(lo <= hi for lo, hi in zip(b["lower"], b["upper"])) == 365
     pipeline.save_results(res, str(tmp_path / "model_results.json"))
     assert json.loads((tmp_path / "model_results.json").read_text())["predictions"]["0_1"]["bayesian"]["metrics"]["rmse"] > 0
+
+
+@pytest.mark.gpu
+def test_trainer_on_a_device_that_is_not_current():
+    """main.py:236-238 puts task i on device i % n while another device may be current: the trainer and the TFT engine
+    make their own device current around every C-ABI call (a context refuses a foreign current device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from mcmc_amd.engine import param_count
+    from mcmc_amd.train import EnsembleTrainer
+    torch.cuda.set_device(0)
+    d1 = torch.device("cuda", 1)
+    P = param_count(11)
+    tr = EnsembleTrainer(torch.randn(2, P, device=d1) * 0.05, torch.full((2, P), -3.0, device=d1), 11, num_samples=3)
+    loss = tr.step(torch.randn(2, 32, 11, device=d1), torch.randn(2, 32, device=d1), 1e-3, seed=1)
+    assert torch.isfinite(loss).all() and torch.cuda.current_device() == 0

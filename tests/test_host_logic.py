@@ -412,3 +412,16 @@ def test_one_cycle_schedule_equals_torch_stepwise():
             sched.step()
     assert one_cycle_schedule(epochs, spe) == (lrs, b1s)  # cached copy, fresh lists
     assert lrs[0] == pytest.approx(0.01 / 25) and max(lrs) == pytest.approx(0.01, rel=1e-3) and b1s[0] == pytest.approx(0.95)
+
+
+def test_dropin_utils_exports_what_main_imports(capsys):
+    """main.py:12 does `from utils import evaluate_predictions`; bayesian_ensemble.py:6 `from utils import peak_weighted_loss`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dropin_utils", os.path.join(ROOT, "dropin", "utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.peak_weighted_loss)
+    out = mod.evaluate_predictions(np.array([100.0, 200.0]), np.array([110.0, 190.0]), "Bayesian")
+    assert abs(out["rmse"] - 10.0) < 1e-9 and abs(out["mape"] - 7.5) < 1e-9
+    printed = capsys.readouterr().out
+    assert "Bayesian Performance:" in printed and "RMSE: 10.00" in printed and "MAPE: 7.50%" in printed
