@@ -175,6 +175,15 @@ int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n,
                        const double* stats, const double* part, float alpha, float beta,
                        float grad_scale, float* grad, mcmc_stream_t stream);
 
+/* The same loss and gradient for ONE rank (n = N, the reference's own use: utils.py:7-28 is called on whole tensors)
+ * in one call: the three passes back to back, their partial sums as per-workgroup slots of `workspace`
+ * (mcmc_loss_workspace_bytes() bytes of device memory, 8-byte aligned, contents irrelevant before and after) that
+ * every later pass re-reduces in a fixed order - no atomics, nothing to zero, bitwise reproducible.
+ *   loss [1] device fp32 = mean(d^2 w);  grad [n] = grad_scale * dL/dp, or NULL for the forward value alone. */
+int64_t mcmc_loss_workspace_bytes(void);
+int mcmc_loss_fused(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta,
+                    float grad_scale, float* loss, float* grad, void* workspace, mcmc_stream_t stream);
+
 /* ---- next row: one training step of all members --------------------------- */
 /* Replaces the inner loop of GPUBayesianEnsemble.train (bayesian_ensemble.py:160-181) for all
  * n_members at once (the reference trains them one after the other, :135).  Pairs are indexed

@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 14; }
+int mcmc_abi_version(void) { return 15; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -281,6 +281,19 @@ int mcmc_loss_backward(mcmc_ctx* ctx, const float* p, const float* t, int64_t n,
     if (n == 0) return MCMC_OK;
     MCMC_REQUIRE(grad && aligned16(grad), "grad is NULL or not 16-byte aligned");
     return launch_loss_backward(ctx, p, t, n, n_total, stats, part, alpha, beta, grad_scale, grad, (hipStream_t)stream);
+}
+
+int64_t mcmc_loss_workspace_bytes(void) { return loss_workspace_doubles() * (int64_t)sizeof(double); }
+
+int mcmc_loss_fused(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta, float grad_scale, float* loss,
+                    float* grad, void* workspace, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n >= 1, "n must be >= 1");
+    if (int rc = check_loss(p, t, n, n)) return rc;
+    MCMC_REQUIRE(loss, "loss is NULL");
+    MCMC_REQUIRE(!grad || aligned16(grad), "grad must be 16-byte aligned");
+    MCMC_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace is NULL or not 8-byte aligned");
+    return launch_loss_fused(ctx, p, t, n, alpha, beta, grad_scale, loss, grad, (double*)workspace, (hipStream_t)stream);
 }
 
 // ---- training step (row f1) ----------------------------------------------------------------------
