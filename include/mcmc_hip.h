@@ -184,6 +184,18 @@ int64_t mcmc_loss_workspace_bytes(void);
 int mcmc_loss_fused(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta,
                     float grad_scale, float* loss, float* grad, void* workspace, mcmc_stream_t stream);
 
+/* mcmc_loss_fused without a workspace argument and without any allocation.  It has NO counterpart in the reference: it
+ * is for callers that cannot allocate - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * The per-workgroup partial sums live in a 40 KB file-scope device array that every GPU the library runs on holds until the
+ * process ends (its per-device address is taken once, in mcmc_ctx_create).  Same kernels, same bits as mcmc_loss_fused.
+ * n <= MCMC_LOSS_STATIC_MAX_N (larger: MCMC_EINVAL).  All calls on one GPU share that array: calls that overlap on one GPU
+ * (different streams or threads) race; calls in stream order are safe, and nothing needs clearing between them (every slot
+ * a call reads it has written first). */
+#define MCMC_LOSS_STATIC_MAX_N (((int64_t)1 << 31) - 1)
+int mcmc_loss_fused_static(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha,
+                           float beta, float grad_scale, float* loss, float* grad,
+                           mcmc_stream_t stream);
+
 /* ---- next row: one training step of all members --------------------------- */
 /* Replaces the inner loop of GPUBayesianEnsemble.train (bayesian_ensemble.py:160-181) for all
  * n_members at once (the reference trains them one after the other, :135).  Pairs are indexed

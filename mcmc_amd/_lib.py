@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16, DT_BF16_FAST = 0, 1, 2
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class MCMCLibraryError(RuntimeError):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "mcmc_loss_backward": (_i32, [_ctx_p, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _f32, _f32, _f32, _ptr, _stream]),
     "mcmc_loss_workspace_bytes": (_i64, []),
     "mcmc_loss_fused": (_i32, [_ctx_p, _ptr, _ptr, _i64, _f32, _f32, _f32, _ptr, _ptr, _ptr, _stream]),
+    "mcmc_loss_fused_static": (_i32, [_ctx_p, _ptr, _ptr, _i64, _f32, _f32, _f32, _ptr, _ptr, _stream]),
     "mcmc_train_sigma": (_i32, [_ctx_p, _ptr, _ptr, _i64, _stream]),
     "mcmc_train_sample": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr, _u64, _ptr, _ptr, _ptr, _stream]),
     "mcmc_train_forward": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _stream]),

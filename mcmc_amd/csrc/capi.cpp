@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 15; }
+int mcmc_abi_version(void) { return 16; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -49,6 +49,15 @@ int mcmc_ctx_create(int device, mcmc_ctx** out) {
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_error(MCMC_EHIP, "device %d is %s; this library holds gfx950 (MI355X) code only", device, prop.gcnArchName);
+    {  // per-device address of the allocation-free entry point's scratch, taken with this device current
+        int prev = -1;
+        e = hipGetDevice(&prev);
+        if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDevice: %s", hipGetErrorString(e));
+        if (prev != device && (e = hipSetDevice(device)) != hipSuccess) return set_error(MCMC_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        const int rc = loss_static_init(device);
+        if (prev != device) (void)hipSetDevice(prev);
+        if (rc) return rc;
+    }
     mcmc_ctx* c = new (std::nothrow) mcmc_ctx;
     if (!c) return set_error(MCMC_EHIP, "out of host memory");
     c->magic = kCtxMagic;
@@ -294,6 +303,18 @@ int mcmc_loss_fused(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, fl
     MCMC_REQUIRE(!grad || aligned16(grad), "grad must be 16-byte aligned");
     MCMC_REQUIRE(workspace && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace is NULL or not 8-byte aligned");
     return launch_loss_fused(ctx, p, t, n, alpha, beta, grad_scale, loss, grad, (double*)workspace, (hipStream_t)stream);
+}
+
+int mcmc_loss_fused_static(mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta, float grad_scale,
+                           float* loss, float* grad, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    MCMC_REQUIRE(n >= 1, "n must be >= 1");
+    MCMC_REQUIRE(n <= MCMC_LOSS_STATIC_MAX_N, "n = %lld exceeds MCMC_LOSS_STATIC_MAX_N (%lld): use mcmc_loss_fused with a workspace",
+                 (long long)n, (long long)MCMC_LOSS_STATIC_MAX_N);
+    if (int rc = check_loss(p, t, n, n)) return rc;
+    MCMC_REQUIRE(loss, "loss is NULL");
+    MCMC_REQUIRE(!grad || aligned16(grad), "grad must be 16-byte aligned");
+    return launch_loss_fused_static(ctx, p, t, n, alpha, beta, grad_scale, loss, grad, (hipStream_t)stream);
 }
 
 // ---- training step (row f1) ----------------------------------------------------------------------

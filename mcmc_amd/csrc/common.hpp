@@ -73,6 +73,10 @@ int64_t loss_workspace_doubles();
 int launch_loss_fused(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta, float grad_scale,
                       float* loss, float* grad, double* ws, hipStream_t s);
 
+int loss_static_init(int device);
+int launch_loss_fused_static(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta, float grad_scale,
+                             float* loss, float* grad, hipStream_t s);
+
 int launch_train_sigma(const float* rho, float* sigma, int64_t n, hipStream_t s);
 int launch_train_early_stop(const double* epoch_loss, double* best, int64_t* bad, uint8_t* active, int M, int64_t patience, hipStream_t s);
 int launch_train_sample(const float* mu, const float* sigma, int M, int S, int F, int noise_mode, const float* eps_in, uint64_t seed,

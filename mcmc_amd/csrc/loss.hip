@@ -354,6 +354,14 @@ __global__ __launch_bounds__(kBlock) void fused_backward_kernel(const float* __r
 }
 
 constexpr int kMaxLossGrid = 1024;  // 4 workgroups per CU on 256 CUs
+constexpr int kMaxDevices = 64;
+
+// Scratch of the allocation-free entry point (mcmc_loss_fused_static): the workspace of mcmc_loss_fused as a file-scope
+// device array, 40 KB on every GPU the library runs on, until the process ends.  In host code the NAME is a stand-in,
+// not a device address: the per-device address comes from hipGetSymbolAddress at context creation and only that pointer
+// is ever handed to a kernel.
+static __device__ __align__(256) double scratch[5 * kMaxLossGrid];
+static double* g_scratch_ptr[kMaxDevices];  // [device] -> address of that device's copy of `scratch`
 
 inline int loss_grid(const mcmc_ctx* ctx, int64_t n) {
     int64_t b = (n / 4 + kBlock - 1) / kBlock;
@@ -386,6 +394,25 @@ int launch_loss_backward(const mcmc_ctx* ctx, const float* p, const float* t, in
 }
 
 int64_t loss_workspace_doubles() { return 5 * (int64_t)kMaxLossGrid; }
+
+// once per device, with that device current (mcmc_ctx_create)
+int loss_static_init(int device) {
+    if (device < 0 || device >= kMaxDevices) return set_error(MCMC_EINVAL, "device %d beyond the %d this library keeps scratch for", device, kMaxDevices);
+    if (g_scratch_ptr[device]) return MCMC_OK;
+    double* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return set_error(MCMC_EHIP, "hipGetSymbolAddress(loss scratch) on device %d: %s", device, hipGetErrorString(e));
+    g_scratch_ptr[device] = ptr;
+    return MCMC_OK;
+}
+
+// the three launches of launch_loss_fused on this device's static scratch: no allocation of any kind
+int launch_loss_fused_static(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta, float grad_scale,
+                             float* loss, float* grad, hipStream_t s) {
+    double* ws = (ctx->device >= 0 && ctx->device < kMaxDevices) ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!ws) return set_error(MCMC_ESTATE, "no static scratch for device %d (context not created by mcmc_ctx_create?)", ctx->device);
+    return launch_loss_fused(ctx, p, t, n, alpha, beta, grad_scale, loss, grad, ws, s);
+}
 
 int launch_loss_fused(const mcmc_ctx* ctx, const float* p, const float* t, int64_t n, float alpha, float beta, float grad_scale,
                       float* loss, float* grad, double* ws, hipStream_t s) {
