@@ -161,12 +161,12 @@ def main():
     if rank == 0:
         fwd = timers.get("forward", [])
         fwd_ms = [a.elapsed_time(b) for a, b, _ in fwd]
-        fwd_units = sum(u for _, _, u in fwd) * B
+        fwd_units = sum(u for _, _, u in fwd)
         fwd_s = sum(fwd_ms) / 1e3
         achieved = FLOP_PER_UNIT * fwd_units / fwd_s / 1e12 if fwd_s > 0 else 0.0
         red = timers.get("reduce_update", [])
         red_s = sum(a.elapsed_time(b) for a, b, _ in red) / 1e3
-        red_units = sum(u for _, _, u in red) * B
+        red_units = sum(u for _, _, u in red)
         out = {
             "metric": "MC predictive samples/sec (member x sample x timestep)",
             "value": units_per_step * args.steps / elapsed,

@@ -135,6 +135,28 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
     const bool loadable = row0 + 3 < ldY;  // the float4 stays inside the row pitch
     const int words = nbins >> 1;
 
+    const bool full_tile = row_base + kRows <= n_rows;  // block-uniform: no per-row bounds checks
+    // The tile's state is read NOW and written at the end: its global round trip (the moments of the rows, and for nbins <=
+    // 128 the tile's [64 x words] block of the histogram, 16 bytes x 4 per thread) hides behind the whole sample stream
+    // instead of standing between the last sample and the first store.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kPre = 4;  // uint4 per thread held across the stream: covers 64 rows x 64 words (128 bins)
+    const int n4 = kRows * words / 4;
+    const bool prefetch = HIST && full_tile && n4 <= kPre * kRows * kWavesR;
+    u32x4 gpre[kPre];
+    if (prefetch) {
+        const u32x4* hg = reinterpret_cast<const u32x4*>(hist + row_base * words);
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i4 = threadIdx.x + u * kRows * kWavesR;
+            gpre[u] = i4 < n4 ? __builtin_nontemporal_load(hg + i4) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    double m1 = 0.0, m2 = 0.0;
+    if (wave == 0 && row_base + lane < n_rows) {
+        m1 = sum[row_base + lane];
+        m2 = sumsq[row_base + lane];
+    }
     float lo[4] = {0, 0, 0, 0}, inv_w[4] = {0, 0, 0, 0};
     if (HIST) {
         for (int i = threadIdx.x; i < kRows * words / 4; i += kRows * kWavesR) reinterpret_cast<uint4*>(lh)[i] = uint4{0u, 0u, 0u, 0u};
@@ -175,7 +197,6 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
     };
     using yes = std::true_type;
     using no = std::false_type;
-    const bool full_tile = row_base + kRows <= n_rows;  // block-uniform: no per-row bounds checks
     if (loadable) {
         if (full_tile) {
             int c = slot;
@@ -217,17 +238,31 @@ __global__ __launch_bounds__(kRows * kWavesR) void reduce_update4_kernel(const f
             a += red[w * kRows + lane];
             b += red[(kWavesR + w) * kRows + lane];
         }
-        sum[row_base + lane] += a;
-        sumsq[row_base + lane] += b;
+        sum[row_base + lane] = m1 + a;
+        sumsq[row_base + lane] = m2 + b;
     }
     if (HIST) {
-        if (full_tile) {
+        if (prefetch) {
+            u32x4* hg = reinterpret_cast<u32x4*>(hist + row_base * words);
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) {
+                const int i4 = threadIdx.x + u * kRows * kWavesR;
+                if (i4 < n4) {
+                    const int rl = (4 * i4) / words, w = (4 * i4) & (words - 1), rot = 2 * (rl >> 2);
+                    const uint32_t* lr = lh + rl * words;
+                    u32x4 g = gpre[u];
+                    g.x += lr[(w + rot) & (words - 1)];
+                    g.y += lr[(w + 1 + rot) & (words - 1)];
+                    g.z += lr[(w + 2 + rot) & (words - 1)];
+                    g.w += lr[(w + 3 + rot) & (words - 1)];
+                    __builtin_nontemporal_store(g, hg + i4);
+                }
+            }
+        } else if (full_tile) {
             // the tile's 64 rows are one contiguous [64 x words] block of the global histogram: 16-byte
             // read-modify-write, four independent loads in flight per thread (the state pass is pure
             // latency otherwise: every workgroup ends with it)
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4* hg = reinterpret_cast<u32x4*>(hist + row_base * words);
-            const int n4 = kRows * words / 4;
             for (int base = threadIdx.x; base < n4; base += 4 * kRows * kWavesR) {
                 u32x4 g[4];
 #pragma unroll

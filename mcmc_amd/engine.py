@@ -402,23 +402,47 @@ def pilot_pairs(cnt: int, M: int) -> int:
     return min(cnt, want)
 
 
-def default_chunk_pairs(ldY: int, wpack_bytes: int, M: int, device) -> int:
-    """Pairs per chunk: the sample buffer Y[C, ldY] fp32 plus the chunk's packed weights within
-    min(32 GiB, a quarter of free HBM).  MI355X has 288 GB: large chunks keep the histogram's
-    per-chunk state pass (read-modify-write of 2*nbins bytes per row plus the workgroups' prologue
-    and flush phases, ~0.7 ms at 3.65 M rows) small beside the sample stream."""
-    free, _ = torch.cuda.mem_get_info(device)
-    budget = min(32 << 30, free // 4)
-    c = max(1, budget // (ldY * 4 + wpack_bytes))
-    if c > M:
-        c -= c % M  # whole rounds of members per chunk
-    return int(min(c, 32768))
+CHUNK_BYTES = 8 << 30  # default bound on the sample buffer Y (the only intermediate that touches HBM)
+ROW_GRANULE = 16384     # the forward kernels' row superblock: row blocks are whole superblocks
+
+
+def plan_chunks(n_pairs_max: int, B: int, chunk_bytes: int, chunk_pairs: Optional[int], chunk_rows: Optional[int],
+                M: int) -> Tuple[int, int]:
+    """(pairs per chunk, rows per block) of the sample buffer Y[pairs, rows] fp32 within ``chunk_bytes``.
+
+    Default: ROW blocks that hold every pair of this rank's shard - a row's samples then meet in ONE reduce
+    launch, so the per-row state (moments + histogram, 288 B per row at 128 bins) is written once per predict
+    instead of read-modify-written once per pair chunk (at 1,024-pair chunks that state pass was 12 % of the
+    reduction's bytes).  Only when even one 16,384-row superblock of all pairs exceeds the bound are the pairs
+    chunked too.  Derived from the LARGEST shard of the group and constants only, so every rank of a sharded
+    predict walks the same row blocks (the pilot all-reduce happens once per block)."""
+    Bp = (B + 63) // 64 * 64
+    if chunk_pairs:
+        cn = max(1, min(chunk_pairs, max(n_pairs_max, 1)))
+    else:
+        cn = max(1, n_pairs_max)
+        if cn * min(Bp, ROW_GRANULE) * 4 > chunk_bytes:
+            cn = max(1, chunk_bytes // (min(Bp, ROW_GRANULE) * 4))
+            if cn > M:
+                cn -= cn % M  # whole rounds of members per chunk
+    if chunk_rows:
+        rb = max(ROW_GRANULE, chunk_rows // ROW_GRANULE * ROW_GRANULE)
+    elif chunk_pairs:
+        rb = Bp  # an explicit pair chunking keeps whole rows (the pre-round-2 shape)
+    else:
+        rb = max(ROW_GRANULE, chunk_bytes // (cn * 4) // ROW_GRANULE * ROW_GRANULE)
+    if rb >= B:
+        return cn, B
+    nb = (B + rb - 1) // rb
+    per = (B + nb - 1) // nb  # balanced blocks of whole superblocks
+    return cn, (per + ROW_GRANULE - 1) // ROW_GRANULE * ROW_GRANULE
 
 
 def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples: int, *, dtype="fp32",
                noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
                q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
-               chunk_pairs: Optional[int] = None, group=False, return_samples: bool = False,
+               chunk_pairs: Optional[int] = None, chunk_rows: Optional[int] = None, chunk_bytes: int = CHUNK_BYTES,
+               group=False, return_samples: bool = False,
                timers: Optional[dict] = None, mc_dropout: bool = False, p_drop: float = 0.1,
                mask_seed: Optional[int] = None) -> PredictResult:
     """Monte Carlo predictive statistics of the ensemble over X.
@@ -475,45 +499,67 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
 
     with torch.cuda.device(eng.device):
         xpack = eng.pack_x(X, dt)
-        ldY = (B + 63) // 64 * 64
         wbytes = eng.wpack_bytes(F, dt)
-        cap = chunk_pairs or default_chunk_pairs(ldY, wbytes, M, eng.device)
-        Cn = max(1, min(cap, max(n_local, 1)))
-        n_pilot = min(pilot_pairs(N, M), cap)  # in every owner's first chunk, whatever the world size
+        xrow_bytes = eng.lib.mcmc_xpack_bytes(32, F, dt) // 32
+        n_max = (N + world - 1) // world  # the largest shard: the chunk plan must not differ between ranks
+        # Philox dropout masks are keyed by the row index inside a launch: that mode keeps whole rows per launch
+        Cplan, Rb = plan_chunks(n_max, B, chunk_bytes, chunk_pairs or (max(1, chunk_bytes // (((B + 63) // 64 * 64) * 4)) if mc_dropout else None),
+                                chunk_rows, M)
+        Cn = max(1, min(Cplan, max(n_local, 1)))
+        # pilot pairs q < n_pilot, whichever ranks own them; bounded by the pair chunk only when pairs ARE chunked, so that
+        # they sit in every owner's first chunk and the choice does not depend on the world size
+        n_pilot = min(pilot_pairs(N, M), Cplan if Cplan < n_max else N)
+        ldY = (min(Rb, B) + 63) // 64 * 64
         Y = torch.empty(Cn, ldY, dtype=torch.float32, device=eng.device)
         wpack = torch.empty(Cn * wbytes, dtype=torch.uint8, device=eng.device)
         st = eng.new_state(B, nbins if nq else 0)
+        pilot = eng.new_state(B) if nq else None
         samples = torch.empty(N, B, dtype=torch.float32, device=eng.device) if return_samples else None
         if return_samples and world > 1:
             raise ValueError("return_samples is a single-process debugging aid")
-
-        first = True
-        for begin in range(q_begin, q_end, Cn):
-            cnt = min(Cn, q_end - begin)
+        hoisted = Cn >= n_local  # one pair chunk: its weights are sampled once and serve every row block
+        if hoisted and n_local:
             with _timed(timers, "sample_weights"):
-                eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
-            with _timed(timers, "forward", cnt):
-                eng.forward(dt, xpack, B, F, wpack, cnt, Y, ldY,
-                            philox_dropout=(seed if mask_seed is None else mask_seed, p_drop, M, S, begin) if mc_dropout else None)
-            if nq and first:
-                # pilot: the moments of global pairs q < n_pilot place every row's histogram.  They sit at the head of
-                # the ranks that own them (rank 0 alone when its shard has >= n_pilot pairs) and in their first chunk
-                # as long as chunk_pairs >= n_pilot; every rank joins the sum, so all ranks bin identically.
-                with _timed(timers, "pilot"):
-                    pilot = eng.new_state(B)
-                    mine = max(0, min(cnt, n_pilot - begin))
-                    if mine:
-                        eng.reduce_update(Y, ldY, mine, B, pilot)
-                    pilot = combine_partials(pilot, group)
-                    eng.set_edges(B, max(pilot.n, 1), pilot.sum, pilot.sumsq, st, range_sigmas)
-            first = False
-            with _timed(timers, "reduce_update", cnt):
-                eng.reduce_update(Y, ldY, cnt, B, st)
-            if samples is not None:
-                samples[pair_global_ids(begin, cnt, M, S, eng.device)] = Y[:cnt, :B]
-        if nq and first:  # a rank without pairs still joins the pilot combine
-            pilot = combine_partials(eng.new_state(B), group)
-            eng.set_edges(B, max(pilot.n, 1), pilot.sum, pilot.sumsq, st, range_sigmas)
+                eng.sample_weights(mu, rho, S, F, q_begin, n_local, mode, eps, seed, dt, wpack)
+
+        def rows_of(t: torch.Tensor, r0: int, rb: int):
+            return t[r0:r0 + rb]
+
+        for r0 in range(0, B, max(Rb, 1)):
+            rb = min(Rb, B - r0)
+            xblk = xpack[r0 * xrow_bytes:]  # row blocks start on whole superblocks: 16-byte aligned
+            blk = ReduceState(0, rows_of(st.sum, r0, rb), rows_of(st.sumsq, r0, rb), nbins=st.nbins)
+            if nq:
+                blk.hist, blk.lo, blk.inv_w = st.hist[r0:r0 + rb], rows_of(st.lo, r0, rb), rows_of(st.inv_w, r0, rb)
+            first = True
+            for begin in range(q_begin, q_end, Cn):
+                cnt = min(Cn, q_end - begin)
+                if not hoisted:
+                    with _timed(timers, "sample_weights"):
+                        eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
+                with _timed(timers, "forward", cnt * rb):
+                    eng.forward(dt, xblk, rb, F, wpack, cnt, Y, ldY,
+                                philox_dropout=(seed if mask_seed is None else mask_seed, p_drop, M, S, begin) if mc_dropout else None)
+                if nq and first:
+                    # pilot: the moments of global pairs q < n_pilot place every row's histogram.  They sit at the head of
+                    # the ranks that own them (rank 0 alone when its shard has >= n_pilot pairs) and in their first chunk;
+                    # every rank joins the sum, so all ranks bin identically.
+                    with _timed(timers, "pilot"):
+                        pblk = ReduceState(0, rows_of(pilot.sum, r0, rb), rows_of(pilot.sumsq, r0, rb))
+                        mine = max(0, min(cnt, n_pilot - begin))
+                        if mine:
+                            eng.reduce_update(Y, ldY, mine, rb, pblk)
+                        pblk = combine_partials(pblk, group)
+                        eng.set_edges(rb, max(pblk.n, 1), pblk.sum, pblk.sumsq, blk, range_sigmas)
+                first = False
+                with _timed(timers, "reduce_update", cnt * rb):
+                    eng.reduce_update(Y, ldY, cnt, rb, blk)
+                if samples is not None:
+                    samples[pair_global_ids(begin, cnt, M, S, eng.device), r0:r0 + rb] = Y[:cnt, :rb]
+            if nq and first:  # a rank without pairs still joins the block's pilot combine
+                pblk = combine_partials(ReduceState(0, rows_of(pilot.sum, r0, rb), rows_of(pilot.sumsq, r0, rb)), group)
+                eng.set_edges(rb, max(pblk.n, 1), pblk.sum, pblk.sumsq, blk, range_sigmas)
+        st.n = n_local
 
         width = (1.0 / st.inv_w) if nq else None
         # exchange step: reduce-scatter over rows -> finalize the own slice -> all-gather the results

@@ -575,3 +575,29 @@ def test_device_generator_equals_cpu():
     Xg, yg = make_series_batch(300, seed=77, device=_dev())
     assert torch.allclose(Xg.cpu(), Xc, rtol=0, atol=2e-6)
     assert torch.allclose(yg.cpu(), yc, rtol=0, atol=1e-4), float((yg.cpu() - yc).abs().max())  # fp32 sums on two devices
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16_fast"])
+def test_row_blocks_equal_whole_rows(dtype):
+    """The default chunking of big jobs - row blocks of whole 16,384-row superblocks that hold every pair, so each row's state
+    is written once - against one block of all rows and against pair chunks: the same samples reach the same rows, so the
+    statistics are identical (moments: fp64 sums of the same values in another association; histogram: exact)."""
+    from mcmc_amd import mc_predict
+    from mcmc_amd.engine import plan_chunks
+    assert plan_chunks(8192, 3_650_000, 8 << 30, None, None, 8) == (8192, 262144)   # config 3, one GPU: 14 blocks of 8 GiB
+    assert plan_chunks(1024, 3_650_000, 8 << 30, None, None, 8) == (1024, 1835008)  # config 4, one of 8 ranks: 2 blocks
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, F, M, S = 40_001, 11, 3, 14
+    P = orc.n_params(F)
+    X = torch.randn(B, F, generator=g).to(d)
+    mu = (torch.randn(M, P, generator=g) * 0.08).to(d)
+    rho = (-3.0 + 0.3 * torch.randn(M, P, generator=g)).to(d)
+    kw = dict(dtype=dtype, seed=5, q_levels=Q, nbins=128, return_samples=True)
+    whole = mc_predict(X, mu, rho, S, **kw)
+    blocks = mc_predict(X, mu, rho, S, chunk_rows=16384, **kw)                    # 3 row blocks, the last one ragged
+    both = mc_predict(X, mu, rho, S, chunk_rows=16384, chunk_pairs=12, **kw)      # row blocks x pair chunks (state read-modify-write)
+    for other in (blocks, both):
+        assert torch.equal(other.samples, whole.samples)
+        assert torch.allclose(other.mean, whole.mean, rtol=0, atol=1e-6) and torch.allclose(other.std, whole.std, rtol=1e-6, atol=1e-7)
+    assert torch.equal(blocks.quantiles, whole.quantiles) and torch.equal(blocks.bin_width, whole.bin_width)

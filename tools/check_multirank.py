@@ -59,6 +59,11 @@ def main():
         assert torch.equal(shard.quantiles, alone.quantiles), (dtype, float((shard.quantiles - alone.quantiles).abs().max()))
         # all ranks hold the same full result
         assert torch.equal(from_rank0(shard.mean), shard.mean.cpu())
+    # row blocks (one pilot all-reduce per block) in the sharded run against one block in the single-rank run
+    Xb = torch.randn(40_001, F, generator=g).to(dev)
+    shard = engine.mc_predict(Xb, mu, rho, 14, dtype="bf16_fast", seed=3, q_levels=q, chunk_rows=16384, group=None)
+    alone = engine.mc_predict(Xb, mu, rho, 14, dtype="bf16_fast", seed=3, q_levels=q, group=solo)
+    assert torch.allclose(shard.mean, alone.mean, rtol=2e-6, atol=2e-6) and torch.equal(shard.quantiles, alone.quantiles)
     # loss, rows split over ranks, global-batch statistics
     N = 4099
     t = torch.randn(N, generator=g)
