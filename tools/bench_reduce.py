@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the streaming reduction (reduce_update) and the loss passes: achieved GB/s.
 
-    python tools/bench_reduce.py --rows 3650000 --pairs 1024 --nbins 128
+    python tools/bench_reduce.py --rows 3650000 --pairs 1024 --nbins 128     # a pair chunk over all rows
+    python tools/bench_reduce.py --rows 262144 --pairs 8192 --no-loss        # the bench's shape: a row block of all pairs
 """
 import argparse
 import os
@@ -35,6 +36,7 @@ def main():
     ap.add_argument("--nbins", type=int, default=128)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--loss-n", type=int, default=36_500_000)
+    ap.add_argument("--no-loss", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     eng = Engine(dev)
@@ -67,6 +69,8 @@ def main():
     ms_c = timeit(lambda: Z.copy_(Y), args.iters)
     print(f"torch copy (r+w)    : {ms_c:.3f} ms  {2 * sample_bytes / ms_c / 1e6:.0f} GB/s")
     del Z, Y
+    if args.no_loss:
+        return
     # loss passes
     from mcmc_amd import peak_weighted_loss
     n = args.loss_n

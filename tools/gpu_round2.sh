@@ -1,0 +1,37 @@
+#!/bin/bash
+# One GPU session of round 2: [tests,] bench, rocprofv3 kernel stats of the bench, PMC passes of the forward and the reduce
+# kernels (one rocprofv3 run per counter set, no trace domains), kernel stats of the loss.  Digest: tools/profile_digest.py.
+# usage: tools/gpu_round2.sh [notests|pmconly]
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=gpurun_out/round2
+if [ "${1:-}" = "pmconly" ]; then
+  mkdir -p $out
+else
+rm -rf $out; mkdir -p $out
+if [ "${1:-}" != "notests" ]; then
+  timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > $out/tests.log 2>&1 || { echo TESTS FAILED; tail -30 $out/tests.log; exit 1; }
+  tail -2 $out/tests.log
+fi
+timeout -k 10 400 python -u bench.py > $out/bench.json 2> $out/bench.err || { echo BENCH FAILED; tail -20 $out/bench.err; exit 1; }
+cat $out/bench.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/prof.log 2>&1 || { echo PROF FAILED; tail -5 $out/prof.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_loss -- python3 tools/bench_loss.py > $out/prof_loss.log 2>&1 || { echo LOSS PROF FAILED; tail -5 $out/prof_loss.log; exit 1; }
+fi
+mkdir -p $out/pmc_fwd $out/pmc_red
+pmc() {  # pmc <dir> <counters...> -- <program args...>
+  local dir=$1; shift; local ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
+  timeout -s KILL 150 rocprofv3 --pmc "${ctrs[@]}" --output-format csv -d "$dir" -- "$@" > "$dir.log" 2>&1 || { echo "pmc pass $dir failed"; tail -5 "$dir.log"; return 1; }
+}
+F="python3 tools/bench_forward.py --dtype bf16_fast --rows 3650000 --pairs 256 --iters 2"
+pmc $out/pmc_fwd/pass1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -- $F || exit 1
+pmc $out/pmc_fwd/pass2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVES -- $F || exit 1
+pmc $out/pmc_fwd/pass3 GRBM_GUI_ACTIVE GRBM_COUNT -- $F || exit 1
+pmc $out/pmc_fwd/pass4 FETCH_SIZE -- $F || exit 1
+pmc $out/pmc_fwd/pass5 WRITE_SIZE -- $F || exit 1
+R="python3 tools/bench_reduce.py --rows 262144 --pairs 8192 --iters 3 --no-loss"
+pmc $out/pmc_red/pass1 FETCH_SIZE -- $R || exit 1
+pmc $out/pmc_red/pass2 WRITE_SIZE -- $R || exit 1
+pmc $out/pmc_red/pass3 GRBM_GUI_ACTIVE GRBM_COUNT -- $R || exit 1
+pmc $out/pmc_red/pass4 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- $R || exit 1
+echo ROUND2 OK
