@@ -64,7 +64,8 @@ class _ShadowAdamW:
             o.step()
 
 
-@pytest.mark.parametrize("F,rows,S", [(11, 32, 3), (7, 13, 2), (11, 45, 2), (24, 1, 2), (11, 2500, 2), (7, 4200, 1)])  # 2500 rows: two row blocks per pair; 4200: four, grid-wide loss kernels
+# 2500 rows: two row blocks per pair; 4200: four, grid-wide loss kernels; 65,536: the config-5 regime (64 row blocks per pair)
+@pytest.mark.parametrize("F,rows,S", [(11, 32, 3), (7, 13, 2), (11, 45, 2), (24, 1, 2), (11, 2500, 2), (7, 4200, 1), (11, 65536, 1)])
 def test_train_step_matches_oracle(F, rows, S):
     from mcmc_amd.train import EnsembleTrainer
     M = 2
