@@ -207,16 +207,50 @@ __global__ __launch_bounds__(256) void sample_weights_bf16_kernel(NoiseSrc ns, i
 
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 
-// sum over one weight row of the bf16 values the MFMA will multiply by (n % 4 == 0, row_off % 4 == 0)
-__device__ __forceinline__ float rowsum_bf16(const NoiseSrc& ns, int m, uint32_t g, int64_t row_off, int n, float scale) {
+// Second pass over the MCMC_DT_BF16_FAST image: every bias absorbs c * (row sum of the bf16 weights the MFMA multiplies
+// by), read back from the image itself (L2-resident: written a moment ago) - 193 rows per pair, one wave each, so no
+// Philox draw is made twice.  Row `o` of layer 1 / 2 lives in fragment lane (o & 31, h) of output tile o >> 5: 16 bytes
+// per k-step and lane half.  Fixed summation order: bitwise reproducible.
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+
+__global__ __launch_bounds__(256) void bias_fixup_bf16_fast_kernel(int F, unsigned char* __restrict__ wpack) {
+    const WPackBF16F L(F);
+    unsigned char* img = wpack + (int64_t)blockIdx.y * L.total;
+    const int lane = threadIdx.x & 63;
+    const int row = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // 0..127 layer 1, 128..191 layer 2, 192 layer 3
+    if (row > H2 + H3) return;
     float s = 0.0f;
-    for (int k = 0; k < n; k += 4) {
-        float w[4];
-        effective_weight4(ns, m, g, row_off + k, w);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) s += bf16_round(w[t] * scale);
+    float* dst;
+    float scale_b = kLog2e;
+    if (row < H2 + H3) {
+        const bool first = row < H2;
+        const int o = first ? row : row - H2;
+        const int steps = first ? 16 : 8;                       // k-steps of 16
+        const int64_t base = (first ? L.l1 : L.l2) + (int64_t)(o >> 5) * steps * 1024;
+        // lane -> (k-step, lane half): 2 * steps fragments of 16 bytes
+        if (lane < 2 * steps) {
+            const int step = lane >> 1, h = lane & 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(img + base + (int64_t)step * 1024 + ((o & 31) + 32 * h) * 16);
+            s = ((bf16_lo(v.x) + bf16_hi(v.x)) + (bf16_lo(v.y) + bf16_hi(v.y))) + ((bf16_lo(v.z) + bf16_hi(v.z)) + (bf16_lo(v.w) + bf16_hi(v.w)));
+        }
+        const int l = 32 * (o >> 5);
+        // position of output o in the [mo][2 h][16 i] bias block: o = 32 mo + f(i, h)
+        const int f = o & 31, hh = (f >> 2) & 1, i = (f & 3) + 4 * (f >> 3);
+        dst = reinterpret_cast<float*>(img + (first ? L.b1 : L.b2)) + l + 16 * hh + i;
+    } else {
+        // layer 3: output row 0 = lanes 0 and 32 of each of the 4 k-steps
+        if (lane < 8) {
+            const int step = lane >> 1, h = lane & 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(img + L.l3 + (int64_t)step * 1024 + (32 * h) * 16);
+            s = ((bf16_lo(v.x) + bf16_hi(v.x)) + (bf16_lo(v.y) + bf16_hi(v.y))) + ((bf16_lo(v.z) + bf16_hi(v.z)) + (bf16_lo(v.w) + bf16_hi(v.w)));
+        }
+        dst = reinterpret_cast<float*>(img + L.b3);
+        scale_b = 1.0f;
     }
-    return s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) *dst = scale_b * (*dst) - kLog2e * s;
 }
 
 // The MCMC_DT_BF16_FAST image in the shifted log2e domain (layout.hpp, forward_bf16.hip): hidden accumulators hold
@@ -282,16 +316,13 @@ __global__ __launch_bounds__(256) void sample_weights_bf16_fast_kernel(NoiseSrc 
                 word = bf16_bits(effective_weight(ns, m, g, idx) * kLn2) | (bf16_bits(effective_weight(ns, m, g, idx + 1) * kLn2) << 16);
             }
         } else if (byte < L.b3) {
+            // b + 1 here; the fix-up kernel below subtracts the row sum of the bf16 weights and scales by c
             const bool first = byte < L.b2;
             const int l = (int)((byte - (first ? L.b1 : L.b2)) / 4);
             const int o = 32 * (l >> 5) + acc_feature(l & 15, (l >> 4) & 1);
-            const int layer = first ? 1 : 2, n_in = first ? H1 : H2;
-            const float b = effective_weight(ns, m, g, flat_b_off(F, layer) + o);
-            const float rs = rowsum_bf16(ns, m, g, flat_w_off(F, layer) + (int64_t)o * n_in, n_in, 1.0f);
-            word = __float_as_uint(kLog2e * (b + 1.0f - rs));
+            word = __float_as_uint(effective_weight(ns, m, g, flat_b_off(F, first ? 1 : 2) + o) + 1.0f);
         } else if (byte == L.b3) {
-            const float b = effective_weight(ns, m, g, flat_b_off(F, 3));
-            word = __float_as_uint(fmaf(-kLog2e, rowsum_bf16(ns, m, g, flat_w_off(F, 3), H3, kLn2), b));
+            word = __float_as_uint(effective_weight(ns, m, g, flat_b_off(F, 3)));
         }
         out[d] = word;
     }
@@ -364,6 +395,8 @@ int launch_sample_weights(const float* mu, const float* rho, int M, int S, int F
             const WPackBF16F L(F);
             hipLaunchKernelGGL(sample_weights_bf16_fast_kernel, dim3(grid_for(L.total / 4, 32), n), dim3(256), 0, s, ns, M, S, F,
                                pair_begin + done, (uint32_t*)wpack + (int64_t)done * (L.total / 4));
+            hipLaunchKernelGGL(bias_fixup_bf16_fast_kernel, dim3((H2 + H3 + 1 + 3) / 4, n), dim3(256), 0, s, F,
+                               (unsigned char*)wpack + (int64_t)done * L.total);
         }
         done += n;
     }

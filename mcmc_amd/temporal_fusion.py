@@ -76,8 +76,31 @@ class TemporalFusionTransformer(nn.Module):
                 p.copy_(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
 
-    def forward(self, x):  # pragma: no cover
-        raise NotImplementedError("use TFTModel.predict / TFTEngine.forward: the HIP path evaluates the last timestep of each window")
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """temporal_fusion.py:120-153: x [batch, time, features] -> [batch, time, 1], eval mode, on the HIP kernels.
+
+        The kernels evaluate the LAST timestep of a window (all that train() and predict() read, :249,:293).  The model has
+        no positional term - the GRNs act per timestep and the attention treats its keys as a set - so the output at
+        timestep t equals the last-timestep output of the same window with rows t and T-1 exchanged: one kernel launch
+        over batch x time such windows gives the reference's whole [batch, time, 1] tensor (attention sums in another
+        key order: equal to ~1e-7)."""
+        if self.training and self.p_drop > 0:
+            raise RuntimeError("TemporalFusionTransformer.forward runs in eval mode on the HIP path (call .eval()); "
+                               "train-mode steps go through TFTModel.train / TFTEngine.step")
+        x = x.rename(None) if x.has_names() else x
+        if x.dim() != 3 or x.shape[-1] != self.num_features:
+            raise ValueError(f"Expected {self.num_features} features, got {x.shape[-1]}")
+        if not x.is_cuda:
+            raise RuntimeError(f"x must live on a HIP device (got {x.device}); mcmc_amd has no CPU path")
+        B, T, F = x.shape
+        idx = torch.arange(T, device=x.device).repeat(T, 1)      # idx[t] = window order for output timestep t
+        t = torch.arange(T, device=x.device)
+        idx[t, t], idx[t, T - 1] = T - 1, t                      # rows t and T-1 exchanged
+        windows = x.to(torch.float32)[:, idx, :].reshape(B * T * T, F).contiguous()   # [B, T(out), T(row), F]
+        start = (torch.arange(B * T, device=x.device, dtype=torch.int32) * T)
+        te = TFTEngine(self.flat_parameters().to(x.device), F, T, p_drop=self.p_drop, max_windows=1)
+        out = te.forward(windows, start)
+        return out.view(B, T, 1).refine_names("batch", "time", "features")
 
 
 @device_guarded

@@ -46,6 +46,12 @@ def test_tft_eval_forward_and_predict_match_reference(golden):
     np.testing.assert_allclose(pred, z["predict"], rtol=0, atol=1e-5)
     with pytest.raises(ValueError):
         m.predict(torch.from_numpy(z["X"])[:, :5])
+    # the module's own forward: the reference's whole [batch, time, 1] output (temporal_fusion.py:120-153)
+    full = m.model.eval()(torch.from_numpy(z["raw_batch"]).to(DEV))
+    assert full.names == ("batch", "time", "features") and tuple(full.shape) == z["raw_out"].shape
+    np.testing.assert_allclose(full.rename(None).cpu().numpy(), z["raw_out"], rtol=0, atol=1e-5)
+    with pytest.raises(ValueError):
+        m.model(torch.zeros(2, 30, F + 1, device=DEV))
 
 
 @pytest.mark.parametrize("step", [0, 1])

@@ -34,8 +34,9 @@ int main(int argc, char** argv) {
     const int64_t rows = argc > 1 ? atoll(argv[1]) : 365000;
     const int pairs = argc > 2 ? atoi(argv[2]) : 1024;
     const int iters = argc > 3 ? atoi(argv[3]) : 5;
+    const bool fast = argc > 4 ? atoi(argv[4]) != 0 : true;  // MCMC_DT_BF16_FAST (default) or the exact-ELU kernel
     const int F = 11;
-    const mcmc::WPackBF16 L(F);
+    struct { int K0; int64_t total; } L = {mcmc::k0_pad(F, mcmc::DT_BF16), fast ? mcmc::WPackBF16F(F).total : mcmc::WPackBF16(F).total};
     const int64_t padded = mcmc::rows_pad(rows), ldY = (rows + 63) / 64 * 64;
     // random bf16 in roughly [-0.25, 0.25] for weights, [-2, 2] for inputs
     std::vector<unsigned short> hx(padded * L.K0), hw((size_t)pairs * L.total / 2);
@@ -54,12 +55,12 @@ int main(int argc, char** argv) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
+    if (mcmc::launch_forward_bf16(nullptr, fast, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
     CK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int i = 0; i < iters; ++i) {
         CK(hipEventRecord(a, 0));
-        if (mcmc::launch_forward_bf16(nullptr, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
+        if (mcmc::launch_forward_bf16(nullptr, fast, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
         CK(hipEventRecord(b, 0));
         CK(hipEventSynchronize(b));
         float ms;
@@ -67,6 +68,6 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double units = (double)rows * pairs;
-    printf("rows=%lld pairs=%d best %.3f ms  %.1f TFLOP/s(alg)\n", (long long)rows, pairs, best, units * 87680.0 / best / 1e9);
+    printf("%s rows=%lld pairs=%d best %.3f ms  %.1f TFLOP/s(alg)\n", fast ? "fast " : "exact", (long long)rows, pairs, best, units * 87680.0 / best / 1e9);
     return 0;
 }
