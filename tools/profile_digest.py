@@ -77,7 +77,8 @@ def main():
                    "FETCH_SIZE_KB": fwd[(k, "FETCH_SIZE")], "WRITE_SIZE_KB": fwd[(k, "WRITE_SIZE")],
                    "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled; WRITE_SIZE exact",
                    "hbm_bytes_per_launch_measured": hbm, "units_per_launch_measured": units, "hbm_bytes_per_unit": hbm / units,
-                   "algorithmic_bytes_per_unit": 4 + 32.0 * 3_650_016 / units + 95232.0 / 3_650_000,
+                   "algorithmic_bytes_per_unit": 4 + 95232.0 / 16384 + 32.0 / 256,
+                   "algorithmic_bytes_model": "4 B output + the pair's 95,232 B weight image staged once per 16,384-row superblock + 32 B of X per row shared by the launch's 256 pairs",
                    "SQ_INSTS_MFMA": fwd.get((k, "SQ_INSTS_MFMA")), "SQ_INSTS_VALU": fwd.get((k, "SQ_INSTS_VALU")),
                    "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": fwd.get((k, "GRBM_GUI_ACTIVE"))},
                   open(os.path.join(prof, f"{tag}_pmc_forward.json"), "w"), indent=1)
