@@ -601,3 +601,32 @@ def test_row_blocks_equal_whole_rows(dtype):
         assert torch.equal(other.samples, whole.samples)
         assert torch.allclose(other.mean, whole.mean, rtol=0, atol=1e-6) and torch.allclose(other.std, whole.std, rtol=1e-6, atol=1e-7)
     assert torch.equal(blocks.quantiles, whole.quantiles) and torch.equal(blocks.bin_width, whole.bin_width)
+
+
+@pytest.mark.parametrize("scale_x", [30.0, 1000.0])
+def test_bf16_fast_extreme_preactivations(scale_x):
+    """The exponent-field ELU far outside the trained range: inputs scaled so that pre-activations reach +-10^2 .. 10^4
+    (deeply saturated negative branch: the constructed bits clamp at 0; large positive: the linear branch wins the integer
+    max).  Outputs stay finite and follow the fp32 oracle like the exact bf16 kernel does (bf16 relative error of large
+    activations dominates both)."""
+    from mcmc_amd import mc_predict
+    g = torch.Generator().manual_seed(9)
+    F, B, M, S = 11, 257, 2, 4
+    P = orc.n_params(F)
+    X = torch.randn(B, F, generator=g) * scale_x
+    mu = torch.zeros(M, P)
+    for m in range(M):
+        for (wo, bo, k_in, k_out) in orc.param_offsets(F):
+            mu[m, wo:wo + k_in * k_out] = torch.randn(k_in * k_out, generator=g) * (2.0 / k_in) ** 0.5
+            mu[m, bo:bo + k_out] = 0.1 * torch.randn(k_out, generator=g)
+    rho = torch.full((M, P), -3.0)
+    eps = torch.randn(M, S, P, generator=g)
+    ref = orc.predict_all(X, mu, rho, eps).numpy()
+    d = _dev()
+    errs = {}
+    for dtype in ("bf16", "bf16_fast"):
+        res = mc_predict(X.to(d), mu.to(d), rho.to(d), S, dtype=dtype, noise="injected", eps=eps.reshape(-1, P).to(d), return_samples=True)
+        got = res.samples.cpu().numpy()
+        assert np.isfinite(got).all(), dtype
+        errs[dtype] = float(np.max(np.abs(got - ref)) / np.abs(ref).max())
+    assert errs["bf16"] <= 2e-2 and errs["bf16_fast"] <= 2e-2, errs
