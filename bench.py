@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--chunk-pairs", type=int, default=0)
     ap.add_argument("--chunk-gib", type=float, default=8.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-balance", action="store_true", help="N > 1: equal pair shards instead of shards by the speed measured in the last warm-up step")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-ELU step and the loss block (profiling runs)")
     args = ap.parse_args()
 
@@ -177,6 +178,11 @@ def main():
     kw = dict(noise="philox", q_levels=(0.025, 0.975), nbins=args.nbins, chunk_pairs=args.chunk_pairs or None,
               chunk_bytes=int(args.chunk_gib * (1 << 30)), group=None if world > 1 else False)
 
+    def kernel_rate(timers, name):
+        ev = timers.get(name, [])
+        ms = [a.elapsed_time(b) for a, b, _ in ev]
+        return sum(ms) / 1e3, sum(u for _, _, u in ev), len(ms)
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -185,7 +191,17 @@ def main():
 
     def timed_steps(dtype, warmup, steps, timers):
         for i in range(warmup):
-            mc_predict(X, mu, rho, args.samples, dtype=dtype, seed=1000 + i, **kw)
+            tw = {}
+            mc_predict(X, mu, rho, args.samples, dtype=dtype, seed=1000 + i, timers=tw, **kw)
+            if world > 1 and i == warmup - 1 and not args.no_balance:
+                # shard the timed steps by measured device speed: devices sustain different clocks under this kernel, and
+                # the step takes as long as the slowest rank (engine.shard_pairs; the statistics do not depend on the split)
+                torch.cuda.synchronize()
+                secs, units, _ = kernel_rate(tw, "forward")
+                rate = torch.tensor([units / secs if secs > 0 else 1.0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+                rates = [torch.zeros_like(rate) for _ in range(world)]
+                dist.all_gather(rates, rate)
+                kw["shard_weights"] = [float(r.item()) for r in rates]
         sync()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -198,11 +214,6 @@ def main():
             elapsed = float(tmax.item())
         assert torch.isfinite(res.mean).all() and torch.isfinite(res.std).all()
         return elapsed
-
-    def kernel_rate(timers, name):
-        ev = timers.get(name, [])
-        ms = [a.elapsed_time(b) for a, b, _ in ev]
-        return sum(ms) / 1e3, sum(u for _, _, u in ev), len(ms)
 
     timers = {}
     elapsed = timed_steps(args.dtype, args.warmup, args.steps, timers)
@@ -248,7 +259,8 @@ def main():
                                 "bytes_model": "4 B per unit (the fp32 sample); the per-row state is written once per predict"},
             "phases_ms_per_step_rank0": phases,
             "dist": {"world": world, "backend": backend if world > 1 else None,
-                     "group_ranks": dist.get_world_size() if world > 1 else 1},
+                     "group_ranks": dist.get_world_size() if world > 1 else 1,
+                     "shard_weights": kw.get("shard_weights")},
         }
         if world == 1 and not args.no_extras:
             if args.dtype == "bf16_fast":

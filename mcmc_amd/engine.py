@@ -94,11 +94,24 @@ def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-def shard_pairs(n_pairs: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous, balanced q-range of ``rank``: [begin, end)."""
-    base, rem = divmod(n_pairs, world)
-    begin = rank * base + min(rank, rem)
-    return begin, begin + base + (1 if rank < rem else 0)
+def shard_pairs(n_pairs: int, rank: int, world: int, weights: Optional[Sequence[float]] = None) -> Tuple[int, int]:
+    """Contiguous q-range of ``rank``: [begin, end).  Balanced by default; with ``weights`` (one positive number per rank,
+    identical on every rank) the shares are proportional to them - MI355X devices sustain clocks up to ~10 % apart under an
+    MFMA-dense kernel, and a sharded predict takes as long as its slowest rank.  Results do not depend on the split: noise is
+    keyed by the global pair id and the pilot pairs are q < n_pilot whoever owns them."""
+    if weights is None:
+        base, rem = divmod(n_pairs, world)
+        begin = rank * base + min(rank, rem)
+        return begin, begin + base + (1 if rank < rem else 0)
+    w = [float(x) for x in weights]
+    if len(w) != world or not all(x > 0.0 and x == x and x != float("inf") for x in w):
+        raise ValueError(f"shard weights must be {world} positive finite numbers, got {list(weights)}")
+    total, acc, bounds = sum(w), 0.0, [0]
+    for x in w[:-1]:
+        acc += x
+        bounds.append(min(n_pairs, max(bounds[-1], int(round(n_pairs * acc / total)))))
+    bounds.append(n_pairs)
+    return bounds[rank], bounds[rank + 1]
 
 
 def pair_global_ids(begin: int, count: int, M: int, S: int, device=None) -> torch.Tensor:
@@ -442,7 +455,7 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
                q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
                chunk_pairs: Optional[int] = None, chunk_rows: Optional[int] = None, chunk_bytes: int = CHUNK_BYTES,
-               group=False, return_samples: bool = False,
+               group=False, shard_weights: Optional[Sequence[float]] = None, return_samples: bool = False,
                timers: Optional[dict] = None, mc_dropout: bool = False, p_drop: float = 0.1,
                mask_seed: Optional[int] = None) -> PredictResult:
     """Monte Carlo predictive statistics of the ensemble over X.
@@ -494,14 +507,15 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     sharded = group is not False and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if sharded else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    q_begin, q_end = shard_pairs(N, rank, world)
+    q_begin, q_end = shard_pairs(N, rank, world, shard_weights if world > 1 else None)
     n_local = q_end - q_begin
 
     with torch.cuda.device(eng.device):
         xpack = eng.pack_x(X, dt)
         wbytes = eng.wpack_bytes(F, dt)
         xrow_bytes = eng.lib.mcmc_xpack_bytes(32, F, dt) // 32
-        n_max = (N + world - 1) // world  # the largest shard: the chunk plan must not differ between ranks
+        # the largest shard: the chunk plan must not differ between ranks
+        n_max = max(e - b for b, e in (shard_pairs(N, r, world, shard_weights if world > 1 else None) for r in range(world)))
         # Philox dropout masks are keyed by the row index inside a launch: that mode keeps whole rows per launch
         Cplan, Rb = plan_chunks(n_max, B, chunk_bytes, chunk_pairs or (max(1, chunk_bytes // (((B + 63) // 64 * 64) * 4)) if mc_dropout else None),
                                 chunk_rows, M)

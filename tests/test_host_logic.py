@@ -168,6 +168,21 @@ def test_shard_pairs_partitions_exactly(n, world):
     assert max(sizes) - min(sizes) <= 1
 
 
+def test_shard_pairs_weighted():
+    from mcmc_amd.engine import shard_pairs
+    w = [1.0, 0.9, 1.1, 1.0, 1.0, 0.95, 1.05, 1.0]
+    spans = [shard_pairs(8192, r, 8, w) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == 8192 and all(spans[r][1] == spans[r + 1][0] for r in range(7))
+    sizes = [e - b for b, e in spans]
+    assert all(abs(sizes[r] - 8192 * w[r] / sum(w)) <= 1.0 for r in range(8))
+    assert [shard_pairs(5, r, 4, [1, 1, 1, 1]) for r in range(4)] == [(0, 1), (1, 2), (2, 4), (4, 5)]  # round-half-even bounds, exact cover
+    assert [shard_pairs(3, r, 4, [100, 1, 1, 1]) for r in range(4)] == [(0, 3), (3, 3), (3, 3), (3, 3)]
+    with pytest.raises(ValueError):
+        shard_pairs(10, 0, 2, [1.0, 0.0])
+    with pytest.raises(ValueError):
+        shard_pairs(10, 0, 2, [1.0])
+
+
 def test_pair_order_is_a_member_interleaved_permutation():
     from mcmc_amd.engine import pair_global_ids
     M, S = 5, 100

@@ -64,6 +64,9 @@ def main():
     shard = engine.mc_predict(Xb, mu, rho, 14, dtype="bf16_fast", seed=3, q_levels=q, chunk_rows=16384, group=None)
     alone = engine.mc_predict(Xb, mu, rho, 14, dtype="bf16_fast", seed=3, q_levels=q, group=solo)
     assert torch.allclose(shard.mean, alone.mean, rtol=2e-6, atol=2e-6) and torch.equal(shard.quantiles, alone.quantiles)
+    # shards proportional to per-rank weights (what bench.py does with measured device speeds): same statistics
+    skew = engine.mc_predict(Xb, mu, rho, 14, dtype="bf16_fast", seed=3, q_levels=q, group=None, shard_weights=[1.0] + [0.6] * (world - 1))
+    assert torch.allclose(skew.mean, alone.mean, rtol=2e-6, atol=2e-6) and torch.equal(skew.quantiles, alone.quantiles)
     # loss, rows split over ranks, global-batch statistics
     N = 4099
     t = torch.randn(N, generator=g)
