@@ -31,10 +31,12 @@ _WS = {}
 
 
 def _workspace(eng: Engine) -> torch.Tensor:
-    """Per-device workspace of mcmc_loss_fused (40 KB; calls on one stream run in order, so one buffer serves them all)."""
-    ws = _WS.get(eng.device.index)
+    """Workspace of mcmc_loss_fused (40 KB) per (device, stream): calls on one stream run in order, so one buffer serves
+    them all; calls on different streams may overlap and get their own."""
+    key = (eng.device.index, torch.cuda.current_stream(eng.device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[eng.device.index] = torch.empty(int(eng.lib.mcmc_loss_workspace_bytes()), dtype=torch.uint8, device=eng.device)
+        ws = _WS[key] = torch.empty(int(eng.lib.mcmc_loss_workspace_bytes()), dtype=torch.uint8, device=eng.device)
     return ws
 
 
