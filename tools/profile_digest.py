@@ -29,7 +29,7 @@ def stats_csv(src_dir, dst, top=14):
     files = glob.glob(os.path.join(src_dir, "**", "*kernel_stats.csv"), recursive=True)
     if not files:
         return False
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))  # gpurun merges sessions: take the newest
     with open(dst, "w") as f:
         f.write("kernel,calls,total_ms,avg_ms,min_ms,max_ms,percent\n")
         for r in rows[:top]:
@@ -40,7 +40,12 @@ def stats_csv(src_dir, dst, top=14):
 
 def pmc(src_dir, filt):
     acc = defaultdict(lambda: [0.0, set()])
-    for f in sorted(glob.glob(os.path.join(src_dir, "pass*", "**", "*counter_collection.csv"), recursive=True)):
+    newest = {}  # per pass directory the newest file (gpurun merges sessions into one tree)
+    for f in glob.glob(os.path.join(src_dir, "pass*", "**", "*counter_collection.csv"), recursive=True):
+        d = os.path.relpath(f, src_dir).split(os.sep)[0]
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in sorted(newest.values()):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if filt not in k:
