@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 FLOP_PER_UNIT = 2 * (11 * 256 + 256 * 128 + 128 * 64 + 64)  # 87,680 at input_dim 11
 PEAK_BF16_DENSE = 2.5e15   # FLOP/s, MI355X_MICROARCH.md chip table (dense, not the 2:1-sparse headline)
 MFMA_CEILING_MEASURED = 2.1e15  # FLOP/s of a bare v_mfma_f32_32x32x16_bf16 stream at the clock the chip holds (profiles/r01_forward_ablation.md)
+# the same stream over operands that toggle like data (random bf16, A fragment from LDS once per two MFMAs as in the kernel),
+# 2 s back to back: the clock is power-managed and gives back more when the operand bits move (profiles/r02_mfma_data_ceiling.txt)
+MFMA_CEILING_DATA = 1.562e15
 PEAK_HBM = 8.0e12          # B/s spec
 KERNEL_OF = {"bf16": "forward_bf16_exact_kernel", "bf16_fast": "forward_bf16_fast_kernel", "fp32": "forward_f32_kernel"}
 
@@ -251,7 +254,9 @@ def main():
                          "traffic_source": "profiles/r02_pmc_forward.json (PMC bytes per unit of a separate rocprofv3 run) x this run's units per launch",
                          "launches": fwd_n, "avg_launch_ms": fwd_s * 1e3 / fwd_n if fwd_n else None, "flop_per_unit": FLOP_PER_UNIT,
                          "measured_bare_mfma_ceiling": MFMA_CEILING_MEASURED / 1e12,
-                         "frac_of_measured_ceiling": achieved * 1e12 / MFMA_CEILING_MEASURED},
+                         "frac_of_measured_ceiling": achieved * 1e12 / MFMA_CEILING_MEASURED,
+                         "measured_data_mfma_ceiling": MFMA_CEILING_DATA / 1e12,
+                         "frac_of_data_ceiling": achieved * 1e12 / MFMA_CEILING_DATA},
             "roofline_reduce": {"bound": "hbm", "kernel": "reduce_update4_kernel", "achieved": red_gbps, "peak": PEAK_HBM / 1e9,
                                 "unit": "GB/s", "frac": red_gbps / (PEAK_HBM / 1e9),
                                 "traffic": red_bpu * red_units / max(red_n, 1) if red_bpu else None,

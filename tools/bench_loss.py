@@ -4,7 +4,8 @@
     python tools/bench_loss.py [--n 36500000] [--iters 20]
 
 Times (events on the launch stream) the data-parallel three-call path (mcmc_loss_stats / _forward / _backward, fp64 atomics,
-caller-zeroed sums) and the single-rank one-call path (mcmc_loss_fused) at the config-5 total (100k series x 365) and at the
+caller-zeroed sums), the single-rank one-call path (mcmc_loss_fused: one persistent launch that keeps part of the slice on chip)
+and its three-launch form (mcmc_loss_fused_static) at the config-5 total (100k series x 365) and at the
 per-GPU share of it (1/8).  Prints one JSON line per size: ms, GB/s of the 20 B/element algorithmic bytes and
 their fraction of the 8 TB/s HBM spec.  rocprofv3 target for profiles/r02_loss_kernel_stats.csv."""
 import argparse
@@ -63,12 +64,15 @@ def main():
         def fused():
             _lib.check(lib.mcmc_loss_fused(h, _p(p), _p(t), n, 2.0, 0.5, 1.0, _p(loss), _p(grad), _p(ws), _stream()), "fused")
 
+        def fused_static():  # the three launches of round 2's first half, on the library's static scratch
+            _lib.check(lib.mcmc_loss_fused_static(h, _p(p), _p(t), n, 2.0, 0.5, 1.0, _p(loss), _p(grad), _stream()), "fused_static")
+
         def autograd():
             pr = p.detach().requires_grad_(True)
             peak_weighted_loss(pr, t).backward()
 
         out = {"n": n, "algorithmic_bytes": 20 * n}
-        for name, fn in (("three_calls", three_calls), ("fused", fused), ("autograd_wrapper", autograd)):
+        for name, fn in (("three_calls", three_calls), ("fused", fused), ("fused_static", fused_static), ("autograd_wrapper", autograd)):
             ms = timed(fn, args.iters)
             gbps = 20 * n / ms / 1e6
             out[name] = {"ms": round(ms, 4), "GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000.0, 3)}
