@@ -357,6 +357,17 @@ int mcmc_tft_backward_saved(mcmc_ctx* ctx, const float* X, int64_t n_rows, const
                             const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
                             float p_drop, const float* delta, float* dP, const float* act,
                             mcmc_stream_t stream);
+/* loss = peak_weighted_loss(pred, yb) (:250-251 -> utils.py:7-28) and loss.backward() (:252) in ONE launch: every
+ * window's workgroup repeats the batch's two loss reductions over pred [n_windows] / yb [n_windows] in its prologue and
+ * derives its own dLoss/dpred (the arithmetic of mcmc_train_loss with n_members = n_samples = 1, no delta buffer);
+ * workgroup 0 stores loss[0] and, if loss_acc is not NULL, adds it to the fp64 epoch sum loss_acc[0] (:257).
+ * act: the activations mcmc_tft_forward_save left, or NULL to recompute the forward pass as mcmc_tft_backward does. */
+int mcmc_tft_backward_loss(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows,
+                           int seq_len, int num_features, const float* P, const float* PT, int mask_mode,
+                           const uint8_t* mask_feature, const uint8_t* mask_temporal,
+                           const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
+                           float p_drop, const float* pred, const float* yb, float alpha, float beta,
+                           float* loss, double* loss_acc, float* dP, const float* act, mcmc_stream_t stream);
 /* grad = sum over the n_partials rows of dP; clip_grad_norm_(max_norm) (:254); torch's AdamW step
  * (:255) on a flat parameter vector.  norm_scratch: fp64 [mcmc_flat_norm_blocks()]. */
 int mcmc_flat_norm_blocks(void);

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16, DT_BF16_FAST = 0, 1, 2
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class MCMCLibraryError(RuntimeError):
@@ -99,6 +99,8 @@ SIGNATURES = {
                                        _ptr, _stream]),
     "mcmc_tft_backward": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr,
                                  _stream]),
+    "mcmc_tft_backward_loss": (_i32, [_ctx_p, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr,
+                                      _f32, _f32, _ptr, _ptr, _ptr, _ptr, _stream]),
     "mcmc_flat_norm_blocks": (_i32, []),
     "mcmc_train_loss_acc": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i64, _f32, _f32, _ptr, _ptr, _ptr, _stream]),
     "mcmc_tft_adamw": (_i32, [_ctx_p, _ptr, _ptr, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _ptr,

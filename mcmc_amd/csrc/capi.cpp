@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 16; }
+int mcmc_abi_version(void) { return 17; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -555,15 +555,15 @@ int mcmc_tft_forward_save(mcmc_ctx* ctx, const float* X, int64_t n_rows, const i
 static int tft_backward_impl(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len, int num_features, const float* P,
                       const float* PT, int mask_mode, const uint8_t* mask_feature, const uint8_t* mask_temporal,
                       const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed, float p_drop, const float* delta, float* dP,
-                      const float* act, mcmc_stream_t stream) {
+                      const float* act, const TftLossFuse* fuse, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_tft(n_windows, seq_len, num_features)) return rc;
     if (int rc = check_tft_masks(mask_mode, mask_feature, mask_temporal, mask_attention, mask_final, p_drop)) return rc;
     if (n_windows == 0) return MCMC_OK;
-    MCMC_REQUIRE(X && start && P && PT && delta && dP, "NULL pointer");
+    MCMC_REQUIRE(X && start && P && PT && (delta || fuse) && dP, "NULL pointer");
     MCMC_REQUIRE(n_rows >= seq_len, "X has %lld rows, fewer than seq_len %d", (long long)n_rows, seq_len);
     return launch_tft_backward(X, n_rows, start, n_windows, seq_len, num_features, P, PT, mask_mode, mask_feature, mask_temporal, mask_attention,
-                               mask_final, seed, p_drop, delta, dP, act, (hipStream_t)stream);
+                               mask_final, seed, p_drop, delta, dP, act, fuse, (hipStream_t)stream);
 }
 
 int mcmc_tft_backward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len, int num_features,
@@ -571,7 +571,7 @@ int mcmc_tft_backward(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32
                       const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed, float p_drop, const float* delta, float* dP,
                       mcmc_stream_t stream) {
     return tft_backward_impl(ctx, X, n_rows, start, n_windows, seq_len, num_features, P, PT, mask_mode, mask_feature, mask_temporal,
-                             mask_attention, mask_final, seed, p_drop, delta, dP, nullptr, stream);
+                             mask_attention, mask_final, seed, p_drop, delta, dP, nullptr, nullptr, stream);
 }
 
 int mcmc_tft_backward_saved(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len,
@@ -580,7 +580,18 @@ int mcmc_tft_backward_saved(mcmc_ctx* ctx, const float* X, int64_t n_rows, const
                             float p_drop, const float* delta, float* dP, const float* act, mcmc_stream_t stream) {
     MCMC_REQUIRE(act || n_windows == 0, "act is NULL");
     return tft_backward_impl(ctx, X, n_rows, start, n_windows, seq_len, num_features, P, PT, mask_mode, mask_feature, mask_temporal,
-                             mask_attention, mask_final, seed, p_drop, delta, dP, act, stream);
+                             mask_attention, mask_final, seed, p_drop, delta, dP, act, nullptr, stream);
+}
+
+int mcmc_tft_backward_loss(mcmc_ctx* ctx, const float* X, int64_t n_rows, const int32_t* start, int n_windows, int seq_len,
+                           int num_features, const float* P, const float* PT, int mask_mode, const uint8_t* mask_feature,
+                           const uint8_t* mask_temporal, const uint8_t* mask_attention, const uint8_t* mask_final, uint64_t seed,
+                           float p_drop, const float* pred, const float* yb, float alpha, float beta, float* loss, double* loss_acc,
+                           float* dP, const float* act, mcmc_stream_t stream) {
+    MCMC_REQUIRE((pred && yb && loss) || n_windows == 0, "pred / yb / loss is NULL");
+    const TftLossFuse fuse{pred, yb, alpha, beta, loss, loss_acc};
+    return tft_backward_impl(ctx, X, n_rows, start, n_windows, seq_len, num_features, P, PT, mask_mode, mask_feature, mask_temporal,
+                             mask_attention, mask_final, seed, p_drop, nullptr, dP, act, &fuse, stream);
 }
 
 int mcmc_flat_norm_blocks(void) { return tft_flat_blocks(); }

@@ -117,9 +117,17 @@ int launch_tft_transpose(const float* P, float* PT, int F, hipStream_t s);
 int launch_tft_forward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                        const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop, float* pred,
                        float* act, hipStream_t s);
+// fuse != nullptr: the backward kernel derives dLoss/dpred itself from pred / yb (no separate loss launch)
+struct TftLossFuse {
+    const float* pred;  // [B] predictions of the forward kernel, or nullptr: read `delta`
+    const float* yb;    // [B] targets
+    float alpha, beta;
+    float* loss;        // [1]
+    double* loss_acc;   // optional [1]
+};
 int launch_tft_backward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                         const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop,
-                        const float* delta, float* dP, const float* act, hipStream_t s);
+                        const float* delta, float* dP, const float* act, const TftLossFuse* fuse, hipStream_t s);
 // PT != nullptr: param is a TFT parameter vector of F features and PT its transposed image, refreshed by the same kernel
 int launch_flat_update(float* param, int64_t n, const float* dP, int B, float* grad, float* am, float* av, double* normsq_part, float lr,
                        float beta1, float beta2, float adam_eps, float weight_decay, float max_norm, int64_t step, float* gnorm,

@@ -19,6 +19,7 @@
 // for the forward) so every global access is lane-contiguous.  fp32 VALU arithmetic: windows are
 // 30 x 64, the step is launch/latency bound.
 #include "common.hpp"
+#include "member_loss.hpp"
 #include "philox.hpp"
 
 namespace mcmc {
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(NT, 1) void tft_forward_kernel(const float* __restr
 __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __restrict__ X, int64_t n_rows, const int* __restrict__ start, int T, int F,
                                                              const float* __restrict__ P, const float* __restrict__ PT, TftMasks ms,
                                                              const float* __restrict__ delta, float* __restrict__ dP,
-                                                             const float* __restrict__ act) {
+                                                             const float* __restrict__ act, TftLossFuse lf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds l = carve(smem);
     Win w;
@@ -699,6 +700,15 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     w.key = (uint32_t)start[blockIdx.x];
     w.T = T;
     const int t = threadIdx.x, o = t & 63, wv = t >> 6, r0 = wv * 8;
+    // dLoss/dpred of this window: read, or derived here - every workgroup repeats the batch's two loss reductions over the
+    // n_windows predictions (a few microseconds) instead of waiting for a separate loss launch
+    float dy;
+    if (lf.pred) {
+        const LossCoef c = member_loss<NT>(lf.pred, lf.yb, 0, 1, (int64_t)gridDim.x, lf.alpha, lf.beta, blockIdx.x == 0, lf.loss, lf.loss_acc);
+        dy = loss_delta(c, lf.pred[blockIdx.x], lf.yb[blockIdx.x]);
+    } else {
+        dy = delta[blockIdx.x];
+    }
     int64_t s0 = start[blockIdx.x];
     if (s0 < 0 || s0 > n_rows) s0 = n_rows;
     const float warm = (act ? 0.0f : touch_params(PT, tft_param_count(F))) + touch_params(P, tft_param_count(F));
@@ -713,7 +723,6 @@ __global__ __launch_bounds__(NT, 1) void tft_backward_kernel(const float* __rest
     keep(warm);
     float* G = dP + (int64_t)blockIdx.x * tft_param_count(F);
     const float sc = ms.mode != 0 ? ms.scale : 1.0f;
-    const float dy = delta[blockIdx.x];
     // ---- read-out (:149-150, last row): dWout, dbout, upstream of the final GRN in tile row 0
     {
         const float* Wo = P + tft_off_out(F);
@@ -926,10 +935,11 @@ int launch_tft_forward(const float* X, int64_t n_rows, const int* start, int B, 
 
 int launch_tft_backward(const float* X, int64_t n_rows, const int* start, int B, int T, int F, const float* P, const float* PT, int mask_mode,
                         const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, const uint8_t* m3, uint64_t seed, float p_drop,
-                        const float* delta, float* dP, const float* act, hipStream_t s) {
+                        const float* delta, float* dP, const float* act, const TftLossFuse* fuse, hipStream_t s) {
     if (int rc = set_lds(tft_backward_kernel, "tft_backward")) return rc;
+    const TftLossFuse lf = fuse ? *fuse : TftLossFuse{nullptr, nullptr, 0.0f, 0.0f, nullptr, nullptr};
     hipLaunchKernelGGL(tft_backward_kernel, dim3(B), dim3(NT), kLdsFloats * sizeof(float), s, X, n_rows, start, T, F, P, PT,
-                       make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop), delta, dP, act);
+                       make_masks(mask_mode, m0, m1, m2, m3, seed, p_drop), delta, dP, act, lf);
     return check_launch("tft_backward");
 }
 

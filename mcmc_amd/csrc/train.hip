@@ -16,6 +16,7 @@
 // within 2e-5 of the reference's fp32 autograd.
 #include "common.hpp"
 #include "dropmask.hpp"
+#include "member_loss.hpp"
 
 namespace mcmc {
 
@@ -70,28 +71,7 @@ __device__ __forceinline__ Lds carve(float* base) {
     return l;
 }
 
-// T3: pred_mean, peak-weighted loss and d loss / d pred (per sample) of one member ---------------------
-// Everything a row's dLoss/dy needs beyond its own (pred, target): the member's global-batch statistics.
-struct LossCoef {
-    float thr, mean_e, am1, g_over_n, scale;
-};
-
-// mean over samples, summed in sample order like torch.mean(0)
-__device__ __forceinline__ float pred_mean(const float* __restrict__ Y, int m, int S, int64_t rows, int64_t r) {
-    float a = 0.0f;
-    for (int s = 0; s < S; ++s) a += Y[((int64_t)m * S + s) * rows + r];
-    return a / (float)S;
-}
-
-// dLoss / d(one sample's prediction) of a row with sample-mean prediction p and target t
-__device__ __forceinline__ float loss_delta(const LossCoef& c, float p, float t) {
-    const float d = p - t;
-    const float k = t > c.thr ? 1.0f : 0.0f;
-    const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
-    const float w = 1.0f + c.am1 * k * (1.0f + g);
-    const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-    return c.scale * (2.0f * d * w + c.am1 * sgn * (k * d * d * g * (1.0f - g) - c.g_over_n));
-}
+// T3: pred_mean, peak-weighted loss and d loss / d pred (per sample) of one member: member_loss.hpp
 
 // T4: backward of one pair: recompute (or reload) the forward tile, then back-propagate ----------------
 // With LossFuse::Y set, the kernel derives dLoss/dy itself: every workgroup of a member repeats the member's two

@@ -176,81 +176,12 @@ __global__ __launch_bounds__(NT, kWgPerCu) void train_forward_kernel(const float
     }
 }
 
-// All NT threads of a workgroup: the two reduction passes of utils.py:17-28 over member m's batch.  `write` selects
-// the one workgroup that stores loss[m] (and adds it to the epoch sum) when several compute the same member.
-__device__ __forceinline__ LossCoef member_loss(const float* __restrict__ Y, const float* __restrict__ ym, int m, int S, int64_t rows,
-                                                float alpha, float beta, bool write, float* __restrict__ loss,
-                                                double* __restrict__ loss_acc) {
-    __shared__ double red[4][NT / 64];
-    __shared__ double tot[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    auto block_sum4 = [&](double (&v)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double x = v[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if (lane == 0) red[i][wave] = x;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            double a = 0.0;
-            for (int w = 0; w < NT / 64; ++w) a += red[threadIdx.x][w];
-            tot[threadIdx.x] = a;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = tot[i];
-        __syncthreads();
-    };
-    const double N = (double)rows;
-    // a thread's first row (its only one at the reference's batch sizes) is loaded once for both passes
-    const bool has0 = threadIdx.x < rows;
-    const float t0 = has0 ? ym[threadIdx.x] : 0.0f, p0 = has0 ? pred_mean(Y, m, S, rows, threadIdx.x) : 0.0f;
-    auto for_rows = [&](auto&& f) {
-        if (has0) f(t0, p0);
-        for (int64_t r = (int64_t)threadIdx.x + NT; r < rows; r += NT) f(ym[r], pred_mean(Y, m, S, rows, r));
-    };
-    double v[4] = {0, 0, 0, 0};
-    for_rows([&](float tf, float p) {
-        const double t = (double)tf;
-        v[0] += t;
-        v[1] += t * t;
-        v[2] += (double)fabsf(p - tf);
-    });
-    block_sum4(v);
-    const double mean_t = v[0] / N;
-    const double var = (v[1] - v[0] * v[0] / N) / (N - 1.0);
-    const double sd = sqrt(var > 0.0 ? var : (var == var ? 0.0 : var));
-    LossCoef c;
-    c.thr = (float)(mean_t + (double)beta * sd);
-    c.mean_e = (float)(v[2] / N);
-    c.am1 = alpha - 1.0f;
-    double w2[4] = {0, 0, 0, 0};
-    for_rows([&](float t, float p) {
-        const float d = p - t;
-        const float k = t > c.thr ? 1.0f : 0.0f;
-        const float g = 1.0f / (1.0f + expf(c.mean_e - fabsf(d)));
-        w2[0] += (double)(d * d * (1.0f + c.am1 * k * (1.0f + g)));
-        w2[1] += (double)(k * d * d * g * (1.0f - g));
-    });
-    block_sum4(w2);
-    if (write && threadIdx.x == 0) {
-        const float lm = (float)(w2[0] / N);
-        loss[m] = lm;
-        if (loss_acc) loss_acc[m] += (double)lm;  // the epoch sum of bayesian_ensemble.py:181, kept on the device
-    }
-    c.g_over_n = (float)(w2[1] / N);
-    c.scale = (float)(1.0 / (N * (double)S));  // d pred_mean / d pred_sample = 1/S
-    return c;
-}
-
 __global__ __launch_bounds__(NT) void train_loss_kernel(const float* __restrict__ Y, const float* __restrict__ yb, int64_t y_stride, int S,
                                                         int64_t rows, float alpha, float beta, float* __restrict__ delta,
                                                         float* __restrict__ loss, double* __restrict__ loss_acc) {
     const int m = blockIdx.x;
     const float* ym = yb + (int64_t)m * y_stride;
-    const LossCoef c = member_loss(Y, ym, m, S, rows, alpha, beta, true, loss, loss_acc);
+    const LossCoef c = member_loss<NT>(Y, ym, m, S, rows, alpha, beta, true, loss, loss_acc);
     for (int64_t r = threadIdx.x; r < rows; r += NT) delta[(int64_t)m * rows + r] = loss_delta(c, pred_mean(Y, m, S, rows, r), ym[r]);
 }
 
@@ -276,7 +207,7 @@ __global__ __launch_bounds__(NT, kWgPerCu) void train_backward_kernel(const floa
     }
     const float* ym = lf.Y ? lf.yb + (int64_t)m * lf.y_stride : nullptr;
     if (lf.Y) {
-        const LossCoef c = member_loss(lf.Y, ym, m, S, rows, lf.alpha, lf.beta, pair % S == 0 && blockIdx.y == 0, lf.loss, lf.loss_acc);
+        const LossCoef c = member_loss<NT>(lf.Y, ym, m, S, rows, lf.alpha, lf.beta, pair % S == 0 && blockIdx.y == 0, lf.loss, lf.loss_acc);
         if (t == 0) lcs = c;  // kept in LDS: the back-propagation below has no registers to spare
         __syncthreads();
     }

@@ -128,7 +128,6 @@ class TFTEngine:
         self.max_windows = max_windows
         self.dP = torch.empty(max_windows, self.n, **f32)
         self.pred = torch.empty(max_windows, **f32)
-        self.delta = torch.empty(max_windows, **f32)
         # the train-mode forward leaves every window's activations here for the backward kernel (124 KB per window)
         self.act = torch.empty(max_windows * int(self.lib.mcmc_tft_act_floats()), **f32)
         self.p_drop, self.weight_decay, self.beta2, self.adam_eps, self.max_norm = p_drop, weight_decay, beta2, adam_eps, max_norm
@@ -191,17 +190,12 @@ class TFTEngine:
         pred = self.pred
         _lib.check(self.lib.mcmc_tft_forward_save(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
                                                   seed & _U64, self.p_drop, _p(pred), _p(self.act), st), "mcmc_tft_forward_save")
-        if loss_acc is None:
-            _lib.check(self.lib.mcmc_train_loss(self.h, _p(pred), _p(yb), 1, 1, B, alpha, beta, _p(self.delta), _p(self.loss), st),
-                       "mcmc_train_loss")
-        else:
-            if loss_acc.dtype != torch.float64 or loss_acc.numel() != 1 or not loss_acc.is_cuda:
-                raise ValueError("loss_acc must be an fp64 [1] device tensor")
-            _lib.check(self.lib.mcmc_train_loss_acc(self.h, _p(pred), _p(yb), 1, 1, B, alpha, beta, _p(self.delta), _p(self.loss),
-                                                    _p(loss_acc), st), "mcmc_train_loss_acc")
-        _lib.check(self.lib.mcmc_tft_backward_saved(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
-                                                    seed & _U64, self.p_drop, _p(self.delta), _p(self.dP), _p(self.act), st),
-                   "mcmc_tft_backward_saved")
+        if loss_acc is not None and (loss_acc.dtype != torch.float64 or loss_acc.numel() != 1 or not loss_acc.is_cuda):
+            raise ValueError("loss_acc must be an fp64 [1] device tensor")
+        # the loss (utils.py:7-28 over the batch's predictions) runs in the prologue of the backward kernel: one launch fewer
+        _lib.check(self.lib.mcmc_tft_backward_loss(self.h, _p(X), X.shape[0], _p(start), B, self.T, self.F, _p(self.P), _p(self.PT), mode, *m,
+                                                   seed & _U64, self.p_drop, _p(pred), _p(yb), alpha, beta, _p(self.loss), _p(loss_acc),
+                                                   _p(self.dP), _p(self.act), st), "mcmc_tft_backward_loss")
         if update:
             self.t += 1
             # clip + AdamW; the same kernel refreshes the transposed image PT (it was current: _transpose() above)

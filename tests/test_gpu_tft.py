@@ -158,9 +158,10 @@ def test_tft_philox_dropout_matches_oracle_masks(golden):
 
 
 def test_tft_saved_activations_equal_recompute(golden):
-    """step() (train-mode forward that saves the windows' activations + backward that reloads them) == the plain
-    forward / backward pair whose backward recomputes the forward pass: predictions, loss and every window's
-    parameter gradient, bit for bit, with Philox dropout live and with a ragged batch after a full one."""
+    """step() (train-mode forward that saves the windows' activations + ONE backward launch that derives the loss and
+    dLoss/dpred in its prologue and reloads the activations: mcmc_tft_backward_loss) == the plain forward / loss / backward
+    trio whose backward recomputes the forward pass: predictions, loss, the epoch-loss sum and every window's parameter
+    gradient, bit for bit, with Philox dropout live and with a ragged batch after a full one."""
     from mcmc_amd import _lib
     from mcmc_amd.engine import _p, _stream
     z = golden("tft_fwd.npz")
@@ -172,7 +173,10 @@ def test_tft_saved_activations_equal_recompute(golden):
     for n_win, seed in ((32, 77), (13, 78)):
         start = torch.randperm(336, generator=g)[:n_win].to(dtype=torch.int32, device=DEV)
         yb = torch.randn(n_win, generator=g).to(DEV)
-        loss = te.step(X, start, yb, 1e-3, 0.9, seed=seed, update=False).clone()
+        acc = torch.full((1,), 0.25, dtype=torch.float64, device=DEV)
+        loss = te.step(X, start, yb, 1e-3, 0.9, seed=seed, update=False, loss_acc=acc).clone()
+        assert float(acc) == 0.25 + float(loss)
+        assert torch.equal(te.step(X, start, yb, 1e-3, 0.9, seed=seed, update=False), loss)  # without the epoch sum
         pred = torch.empty(n_win, device=DEV)
         delta = torch.empty(n_win, device=DEV)
         l2 = torch.empty(1, device=DEV)
