@@ -235,15 +235,31 @@ int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_
                         const float* delta, float* dW, mcmc_stream_t stream);
 /* Large batches (BASELINE config 5: 10^5..10^6 rows per rank and step; the reference's batch is 32 rows,
  * bayesian_ensemble.py:124, so it has no counterpart): each pair's rows are split into row_blocks runs of
- * whole 32-row tiles, one workgroup each, and dW [M*S*row_blocks, P] receives one partial per block
- * (mcmc_train_grad sums them).  mcmc_train_row_blocks(rows) is the split the library recommends (1 up to
- * 2,047 rows).  mcmc_train_forward splits its rows the same way internally. */
+ * whole tiles (64 rows when row_blocks > 1, eight waves per workgroup), one workgroup each, and
+ * dW [M*S*row_blocks, P] receives one partial per block (mcmc_train_grad sums them).
+ * mcmc_train_row_blocks(rows) is the split the library recommends (1 up to 2,047 rows).  mcmc_train_forward
+ * splits its rows the same way internally. */
 int mcmc_train_row_blocks(int64_t rows);
 int mcmc_train_backward_blocks(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim,
                                int n_members, int n_samples, const float* W, const float* WT,
                                int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
                                const uint8_t* mask2, uint64_t mask_seed, float p_drop,
                                const float* delta, int row_blocks, float* dW, mcmc_stream_t stream);
+/* The same forward / backward pair with autograd's saved tensors instead of the recompute (loss.backward() at :178
+ * works on what the forward kept): mcmc_train_forward_save also leaves every tile's activations in
+ * act [M*S*mcmc_train_act_floats(rows)] (1.8 KB per pair and row: 9.5 GB for 80 pairs x 65,536 rows) and
+ * mcmc_train_backward_saved (row_blocks = mcmc_train_row_blocks(rows)) reloads them.  Same numbers, bit for bit, as
+ * mcmc_train_forward / mcmc_train_backward_blocks; 1.2x faster per step when the buffer fits. */
+int mcmc_train_forward_save(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members,
+                            int n_samples, const float* WT, int mask_mode, const uint8_t* mask0,
+                            const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                            float p_drop, float* Y, float* act, mcmc_stream_t stream);
+int mcmc_train_backward_saved(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim,
+                              int n_members, int n_samples, const float* W, const float* WT,
+                              int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
+                              const uint8_t* mask2, uint64_t mask_seed, float p_drop,
+                              const float* delta, int row_blocks, float* dW, const float* act,
+                              mcmc_stream_t stream);
 /* gmu = sum_s dW, grho = sum_s dW*eps*sigma; clip_grad_norm_(max_norm) per member (:179); AdamW
  * with torch's update rule (:180) on members whose active flag is set (NULL = all); refreshes
  * sigma.  step = 1-based step count for the bias corrections.  adam_m/adam_v: [M,2P] (mu then

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16, DT_BF16_FAST = 0, 1, 2
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class MCMCLibraryError(RuntimeError):
@@ -88,6 +88,9 @@ SIGNATURES = {
     "mcmc_train_step": (_i32, [_ctx_p, C.POINTER(TrainBuffers), C.POINTER(TrainHyper), _ptr, _i64, _ptr, _i64, _i64, _i32, _i32, _i32, _i32,
                                _ptr, _u64, _i32, _ptr, _ptr, _ptr, _u64, _ptr, _f32, _f32, _i64, _ptr, _stream]),
     "mcmc_train_act_floats": (_i64, [_i64]),
+    "mcmc_train_forward_save": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _ptr, _stream]),
+    "mcmc_train_backward_saved": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _i32,
+                                         _ptr, _ptr, _stream]),
     "mcmc_train_early_stop": (_i32, [_ctx_p, _ptr, _ptr, _ptr, _ptr, _i32, _i64, _stream]),
     "mcmc_tft_param_count": (_i64, [_i32]),
     "mcmc_tft_transpose": (_i32, [_ctx_p, _ptr, _ptr, _i32, _stream]),

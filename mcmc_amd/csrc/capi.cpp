@@ -35,7 +35,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 17; }
+int mcmc_abi_version(void) { return 18; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -353,15 +353,30 @@ int mcmc_train_sample(mcmc_ctx* ctx, const float* mu, const float* sigma, int n_
     return launch_train_sample(mu, sigma, n_members, n_samples, input_dim, noise_mode, eps_in, seed, eps, W, WT, (hipStream_t)stream);
 }
 
-int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* WT,
-                       int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
-                       float p_drop, float* Y, mcmc_stream_t stream) {
+static int train_forward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* WT,
+                              int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                              float p_drop, float* Y, float* act, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && WT && Y, "NULL pointer");
     return launch_train_forward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y,
-                                nullptr, (hipStream_t)stream);
+                                act, (hipStream_t)stream);
+}
+
+int mcmc_train_forward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* WT,
+                       int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                       float p_drop, float* Y, mcmc_stream_t stream) {
+    return train_forward_impl(ctx, xb, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y, nullptr,
+                              stream);
+}
+
+int mcmc_train_forward_save(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* WT,
+                            int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed,
+                            float p_drop, float* Y, float* act, mcmc_stream_t stream) {
+    MCMC_REQUIRE(act, "act is NULL");
+    return train_forward_impl(ctx, xb, rows, input_dim, n_members, n_samples, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop, Y, act,
+                              stream);
 }
 
 int mcmc_train_loss(mcmc_ctx* ctx, const float* Y, const float* yb, int n_members, int n_samples, int64_t rows, float alpha,
@@ -382,21 +397,22 @@ int mcmc_train_loss_acc(mcmc_ctx* ctx, const float* Y, const float* yb, int n_me
 
 static int train_backward_impl(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
                                const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
-                               uint64_t mask_seed, float p_drop, const float* delta, int row_blocks, float* dW, mcmc_stream_t stream) {
+                               uint64_t mask_seed, float p_drop, const float* delta, int row_blocks, float* dW, const float* act,
+                               mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && W && WT && delta && dW, "NULL pointer");
     MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     return launch_train_backward(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
-                                 delta, row_blocks, dW, nullptr, nullptr, (hipStream_t)stream);
+                                 delta, row_blocks, dW, act, nullptr, (hipStream_t)stream);
 }
 
 int mcmc_train_backward(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
                         const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2,
                         uint64_t mask_seed, float p_drop, const float* delta, float* dW, mcmc_stream_t stream) {
     return train_backward_impl(ctx, xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
-                               delta, 1, dW, stream);
+                               delta, 1, dW, nullptr, stream);
 }
 
 int mcmc_train_row_blocks(int64_t rows) { return train_row_blocks(rows < 0 ? 0 : rows); }
@@ -406,7 +422,18 @@ int mcmc_train_backward_blocks(mcmc_ctx* ctx, const float* xb, int64_t rows, int
                                const uint8_t* mask2, uint64_t mask_seed, float p_drop, const float* delta, int row_blocks, float* dW,
                                mcmc_stream_t stream) {
     return train_backward_impl(ctx, xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
-                               delta, row_blocks, dW, stream);
+                               delta, row_blocks, dW, nullptr, stream);
+}
+
+int mcmc_train_backward_saved(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples,
+                              const float* W, const float* WT, int mask_mode, const uint8_t* mask0, const uint8_t* mask1,
+                              const uint8_t* mask2, uint64_t mask_seed, float p_drop, const float* delta, int row_blocks, float* dW,
+                              const float* act, mcmc_stream_t stream) {
+    MCMC_REQUIRE(act, "act is NULL");
+    MCMC_REQUIRE(row_blocks == train_row_blocks(rows), "row_blocks must be mcmc_train_row_blocks(rows) = %d: the saved activations are laid out "
+                 "by the tile shape the forward launch chose from it (got %d)", train_row_blocks(rows), row_blocks);
+    return train_backward_impl(ctx, xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
+                               delta, row_blocks, dW, act, stream);
 }
 
 int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }

@@ -22,7 +22,6 @@ namespace mcmc {
 
 namespace {
 
-constexpr int TR = 32;         // rows per LDS tile
 // LDS row strides of the [row][feature] tiles: odd, so a column read (32 rows of one feature: the MFMA's B
 // operand) and a row read (32 consecutive features: its A operand) are both bank-conflict-free
 constexpr int SX = 33, S1 = H1 + 1, S2 = H2 + 1, S3 = H3 + 1;
@@ -33,42 +32,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // A[r][h] and B[h][r]; afterwards register i of lane (r, h) holds D[acc_feature(i, h)][r] (layout.hpp).
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
 
-// expm1 for the ELU's negative branch by Kahan's correction, expm1(z) = (u - 1) * z / log(u) with u = exp(z):
-// ~10 instructions (v_exp_f32, v_log_f32, one division) against ocml expm1f's ~45, within 2 ulp of it.
+// expm1 for the ELU's negative branch: exp(z) - 1 where that keeps its relative accuracy (|z| >= 1/16: within 1e-6 of expm1),
+// the degree-4 Taylor polynomial below it (truncation z^4/120 < 1.3e-7 relative).  One v_exp_f32 and six FMAs / selects per
+// element; Kahan's (u - 1) * z / log(u) form used before (2 ulp) cost three transcendentals and ~20 % of the large-batch forward pass.
 __device__ __forceinline__ float elu_neg(float z) {
-    const float u = __expf(z), um1 = u - 1.0f;
-    float r = um1 * __fdividef(z, __logf(u));  // branch-free: the two special cases are selects
-    r = u == 1.0f ? z : r;                     // |z| below half an ulp of 1
-    return um1 == -1.0f ? -1.0f : r;           // exp underflowed
+    const float big = __expf(z) - 1.0f;
+    const float small = z * fmaf(z, fmaf(z, fmaf(z, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
+    return z > -0.0625f ? small : big;
 }
 
 // derivative factor d = elu'(z) * mask * scale recovered from the stored activation
 __device__ __forceinline__ float dfactor(float h, float scale) {
     if (__float_as_uint(h) == 0x80000000u) return 0.0f;  // masked (or padding row)
     return h > 0.0f ? scale : h + scale;                 // z > 0: scale;  z <= 0: exp(z)*scale = h + scale
-}
-
-struct Lds {
-    float* xs;   // [TR][SX]  input tile, columns >= F are zero
-    float* h1;   // [TR][S1]  activations; the backward pass overwrites each tile in place with the gradient
-    float* h2;   // [TR][S2]  w.r.t. its pre-activations once the weight gradient that needs the activations is done
-    float* h3;   // [TR][S3]
-    float* y;    // [TR] outputs, then dLoss/dy in the backward pass
-};
-constexpr int kLdsFloats = TR * (SX + S1 + S2 + S3 + 1);  // 62 KB: two workgroups per CU, forward and backward
-// h1, h2, h3 of one tile are contiguous in LDS: the forward kernel can save them (57.7 KB per pair and tile) so that
-// the backward kernel of a small batch reloads them from L2 instead of recomputing the tile's forward pass
-constexpr int kActFloats = TR * (S1 + S2 + S3);
-static_assert(kActFloats % 4 == 0 && (TR * SX) % 4 == 0, "activation tiles are copied as float4");
-
-__device__ __forceinline__ Lds carve(float* base) {
-    Lds l;
-    l.xs = base;
-    l.h1 = l.xs + TR * SX;
-    l.h2 = l.h1 + TR * S1;
-    l.h3 = l.h2 + TR * S2;
-    l.y = l.h3 + TR * S3;
-    return l;
 }
 
 // T3: pred_mean, peak-weighted loss and d loss / d pred (per sample) of one member: member_loss.hpp
@@ -89,6 +65,7 @@ struct LossFuse {
 // launch has more workgroups than the chip has CUs (large batches); eight waves when every workgroup has a CU to
 // itself (the reference's batch sizes: 50 pairs), where the second wave per SIMD hides the first one's L2 latency.
 #define MCMC_TRAIN_NT 256
+#define MCMC_TRAIN_TR 32
 namespace nt256 {
 #include "train_tiles.hpp"
 }
@@ -97,6 +74,12 @@ namespace nt256 {
 namespace nt512 {
 #include "train_tiles.hpp"
 }
+#undef MCMC_TRAIN_TR
+#define MCMC_TRAIN_TR 64
+namespace nt512r64 {
+#include "train_tiles.hpp"
+}
+#undef MCMC_TRAIN_TR
 #undef MCMC_TRAIN_NT
 constexpr int kWideMaxWorkgroups = 256;  // CUs of an MI355X
 
@@ -350,16 +333,33 @@ static DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const 
     return dm;
 }
 
+// Which build of the tile code runs a launch.  Forward and backward of one step must agree (the saved activations are
+// laid out per tile), so both derive it from the same two numbers.
+enum class Tiles { k256, k512, k512r64 };
+static Tiles pick_tiles(int64_t pairs, int row_blocks) {
+    if (row_blocks > 1) return Tiles::k512r64;  // large batches: 64-row tiles, eight waves, one workgroup per CU
+    return pairs <= kWideMaxWorkgroups ? Tiles::k512 : Tiles::k256;
+}
+
+template <typename K>
+static int set_dyn_lds(K kern, size_t lds, const char* what) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    return MCMC_OK;
+}
+
+#define MCMC_TRAIN_PICK(NS, KERNEL, mode) ((mode) == 1 ? NS::KERNEL<1> : (mode) == 2 ? NS::KERNEL<2> : NS::KERNEL<0>)
+
 int launch_train_forward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* WT, int mask_mode, const uint8_t* m0,
                          const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, float* Y, float* act, hipStream_t s) {
-    const size_t lds = kLdsFloats * sizeof(float);
     const int row_blocks = train_row_blocks(rows);
-    const bool wide = (int64_t)M * S * row_blocks <= kWideMaxWorkgroups;
-    auto kern = wide ? (mask_mode == 1 ? nt512::train_forward_kernel<1> : mask_mode == 2 ? nt512::train_forward_kernel<2> : nt512::train_forward_kernel<0>)
-                     : (mask_mode == 1 ? nt256::train_forward_kernel<1> : mask_mode == 2 ? nt256::train_forward_kernel<2> : nt256::train_forward_kernel<0>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_forward): %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(wide ? nt512::NT : nt256::NT), lds, s, xb, x_stride, rows, F, S, WT,
+    const Tiles tv = pick_tiles((int64_t)M * S, row_blocks);
+    auto kern = tv == Tiles::k512r64 ? MCMC_TRAIN_PICK(nt512r64, train_forward_kernel, mask_mode)
+                : tv == Tiles::k512  ? MCMC_TRAIN_PICK(nt512, train_forward_kernel, mask_mode)
+                                     : MCMC_TRAIN_PICK(nt256, train_forward_kernel, mask_mode);
+    const size_t lds = (tv == Tiles::k512r64 ? nt512r64::kLdsFloats : nt256::kLdsFloats) * sizeof(float);
+    if (int rc = set_dyn_lds(kern, lds, "train_forward")) return rc;
+    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(tv == Tiles::k256 ? 256 : 512), lds, s, xb, x_stride, rows, F, S, WT,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y, act);
     return check_launch("train_forward");
 }
@@ -373,15 +373,15 @@ int launch_train_loss(const float* Y, const float* yb, int64_t y_stride, int M, 
 int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, const float* WT, int mask_mode,
                           const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
                           int row_blocks, float* dW, const float* act, const TrainLossFuse* fuse, hipStream_t s) {
-    const size_t lds = kLdsFloats * sizeof(float);
-    const bool wide = (int64_t)M * S * row_blocks <= kWideMaxWorkgroups;
-    auto kern = wide ? (mask_mode == 1 ? nt512::train_backward_kernel<1> : mask_mode == 2 ? nt512::train_backward_kernel<2> : nt512::train_backward_kernel<0>)
-                     : (mask_mode == 1 ? nt256::train_backward_kernel<1> : mask_mode == 2 ? nt256::train_backward_kernel<2> : nt256::train_backward_kernel<0>);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(train_backward): %s", hipGetErrorString(e));
+    const Tiles tv = pick_tiles((int64_t)M * S, row_blocks);
+    auto kern = tv == Tiles::k512r64 ? MCMC_TRAIN_PICK(nt512r64, train_backward_kernel, mask_mode)
+                : tv == Tiles::k512  ? MCMC_TRAIN_PICK(nt512, train_backward_kernel, mask_mode)
+                                     : MCMC_TRAIN_PICK(nt256, train_backward_kernel, mask_mode);
+    const size_t lds = (tv == Tiles::k512r64 ? nt512r64::kLdsFloats : nt256::kLdsFloats) * sizeof(float);
+    if (int rc = set_dyn_lds(kern, lds, "train_backward")) return rc;
     LossFuse lf{};
     if (fuse) lf = LossFuse{fuse->Y, fuse->yb, fuse->y_stride, fuse->alpha, fuse->beta, fuse->loss, fuse->loss_acc};
-    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(wide ? nt512::NT : nt256::NT), lds, s, xb, x_stride, rows, F, S, W, WT,
+    hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(tv == Tiles::k256 ? 256 : 512), lds, s, xb, x_stride, rows, F, S, W, WT,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, act, lf);
     return check_launch("train_backward");
 }
@@ -425,7 +425,8 @@ int launch_train_update(float* mu, float* rho, float* sigma, int M, int S, int F
 int train_grad_blocks() { return kGradBlocks; }
 
 // floats per pair of the saved-activation buffer for a batch of `rows` rows
-int64_t train_act_floats(int64_t rows) { return (rows + TR - 1) / TR * (int64_t)kActFloats; }
+// (sized for 64-row tiles, which also covers the 32-row builds' [tiles of 32 rows] layout of the same batch)
+int64_t train_act_floats(int64_t rows) { return (rows + 63) / 64 * (int64_t)nt512r64::kActFloats; }
 
 // Row blocks a batch of `rows` rows per member is split into (each pair then runs on that many workgroups):
 // one up to 2,047 rows - the reference's 32-row batches - then one per 1,024 rows, at most 64.

@@ -1,9 +1,36 @@
-// Tile code of the training step (train.hip includes this file once per workgroup size, inside a namespace,
-// with MCMC_TRAIN_NT defined): dense layers on LDS tiles, the forward tile, the loss reductions and the
+// Tile code of the training step (train.hip includes this file once per (workgroup size, rows per tile), inside a
+// namespace, with MCMC_TRAIN_NT and MCMC_TRAIN_TR defined): dense layers on LDS tiles, the forward tile, the loss reductions and the
 // forward / loss / backward kernels.  No include guard on purpose.
 constexpr int NT = MCMC_TRAIN_NT;  // threads per workgroup
 constexpr int NW = NT / 64;
 constexpr int kWgPerCu = NT <= 256 ? 2 : 1;
+constexpr int TR = MCMC_TRAIN_TR;  // rows per LDS tile: 32, or 64 = two MFMA row tiles per pass of the tile code (large batches)
+constexpr int RT = TR / 32;
+static_assert(TR % 32 == 0 && NT >= 8 * TR || TR == 32, "layer 3 gives a row eight threads");
+
+struct Lds {
+    float* xs;   // [TR][SX]  input tile, columns >= F are zero
+    float* h1;   // [TR][S1]  activations; the backward pass overwrites each tile in place with the gradient
+    float* h2;   // [TR][S2]  w.r.t. its pre-activations once the weight gradient that needs the activations is done
+    float* h3;   // [TR][S3]
+    float* y;    // [TR] outputs, then dLoss/dy in the backward pass
+};
+constexpr int kLdsFloats = TR * (SX + S1 + S2 + S3 + 1);  // 62 KB at 32 rows: two workgroups per CU, forward and backward; 124 KB at 64
+// h1, h2, h3 of one tile are contiguous in LDS: the forward kernel can save them (57.7 KB per pair and tile) so that
+// the backward kernel of a small batch reloads them from L2 instead of recomputing the tile's forward pass
+constexpr int kActFloats = TR * (S1 + S2 + S3);
+static_assert(kActFloats % 4 == 0 && (TR * SX) % 4 == 0, "activation tiles are copied as float4");
+
+__device__ __forceinline__ Lds carve(float* base) {
+    Lds l;
+    l.xs = base;
+    l.h1 = l.xs + TR * SX;
+    l.h2 = l.h1 + TR * S1;
+    l.h3 = l.h2 + TR * S2;
+    l.y = l.h3 + TR * S3;
+    return l;
+}
+
 
 // ---- dense layers on LDS tiles, MFMA ---------------------------------------------------------------
 // Z^T[out, row] = b[out] + sum_k WT[k][out] * hin[row][k]; then h = elu(z) * mask * scale -> hout[row][out].
@@ -14,15 +41,19 @@ template <int MODE, int OUT, int IN_STRIDE, int OUT_STRIDE>
 __device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int K, const float* __restrict__ WT,
                                               const float* __restrict__ bias, float* __restrict__ hout, const DropMask& dm, int pair,
                                               int64_t rows, int64_t row_base, int layer) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
-    const bool live = row_base + r < rows;
+    // the wave id as a scalar: tile bases then live in SGPRs and every weight load is (scalar base) + (one per-lane offset)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
+    // a unit = one 32 x 32 output tile: (feature tile mo, row tile rt); wave w owns units w, w + NW, ...
 #pragma unroll 1
-    for (int mo = wave; mo < OUT / 32; mo += NW) {
+    for (int unit = wave; unit < (OUT / 32) * RT; unit += NW) {
+        const int mo = unit / RT, rr = 32 * (unit % RT) + r;  // rr: this lane's row inside the LDS tile
+        const bool live = row_base + rr < rows;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = bias[32 * mo + acc_feature(i, h)];
-        const float* a = WT + 32 * mo + r;
-        const float* b = hin + r * IN_STRIDE;
+        const float* a = WT + 32 * mo;            // uniform
+        const unsigned al = (unsigned)(h * OUT + r);  // this lane's element offset inside every k-step pair
+        const float* b = hin + rr * IN_STRIDE;
         // every weight is used once per tile, so the A stream is bound by L2 latency: issue a batch of loads,
         // then the MFMAs that consume them
         if (K % 32) {  // layer 0: K = input width (<= kMaxInputDim), possibly odd; xs columns >= K are zero
@@ -30,28 +61,48 @@ __device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int
 #pragma unroll
             for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st) {
                 const int k = 2 * st + h;
-                av[st] = k < K ? a[k * OUT] : 0.0f;
+                av[st] = k < K ? a[2 * st * OUT + al] : 0.0f;
                 bv[st] = b[k];
             }
 #pragma unroll
             for (int st = 0; st < (kMaxInputDim + 1) / 2; ++st)
                 if (2 * st < K) acc = mfma2(av[st], bv[st], acc);
         } else {
+            // two register batches of 32 weights: the loads of batch s+1 are in flight while the MFMAs of batch s run,
+            // so only a tile's first batch waits for L2.  The scheduling fences keep hipcc from hoisting both batches'
+            // LDS operand reads to the top (that spilled hundreds of registers).
+            float av0[32], av1[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) av0[u] = a[2 * u * OUT + al];
 #pragma unroll 1
-            for (int s0 = 0; s0 < K / 2; s0 += 32) {
-                float av[32];
+            for (int s0 = 0; s0 < K / 2; s0 += 64) {
+                const bool more1 = s0 + 32 < K / 2, more2 = s0 + 64 < K / 2;
+                if (more1) {
 #pragma unroll
-                for (int u = 0; u < 32; ++u) av[u] = a[(2 * (s0 + u) + h) * OUT];
+                    for (int u = 0; u < 32; ++u) av1[u] = a[2 * (s0 + 32 + u) * OUT + al];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 32; ++u) acc = mfma2(av[u], b[2 * (s0 + u) + h], acc);
+                for (int u = 0; u < 32; ++u) acc = mfma2(av0[u], b[2 * (s0 + u) + h], acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more2) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) av0[u] = a[2 * (s0 + 64 + u) * OUT + al];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more1) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) acc = mfma2(av1[u], b[2 * (s0 + 32 + u) + h], acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         float o[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[i] = acc[i] > 0.0f ? acc[i] : elu_neg(acc[i]);
-        drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row_base + r);
+        drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row_base + rr);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) hout[r * OUT_STRIDE + 32 * mo + acc_feature(i, h)] = live ? o[i] : -0.0f;
+        for (int i = 0; i < 16; ++i) hout[rr * OUT_STRIDE + 32 * mo + acc_feature(i, h)] = live ? o[i] : -0.0f;
     }
 }
 
@@ -59,7 +110,7 @@ __device__ __forceinline__ void dense_forward(const float* __restrict__ hin, int
 template <int OUT, int DZ_STRIDE, int IN_STRIDE>
 __device__ __forceinline__ void weight_grad(const float* __restrict__ dz, const float* __restrict__ hin, int IN, float* __restrict__ g,
                                             bool first) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
     const int n_in = (IN + 31) / 32;
 #pragma unroll 1
     for (int tile = wave; tile < (OUT / 32) * n_in; tile += NW) {
@@ -99,24 +150,44 @@ __device__ __forceinline__ void bias_grad(const float* __restrict__ dz, float* _
 template <int OUT, int IN, int DZ_STRIDE, int IN_STRIDE>
 __device__ __forceinline__ void input_grad(const float* __restrict__ dz, const float* __restrict__ W, const float* hin, float scale,
                                            float* dzin) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, h = lane >> 5;
 #pragma unroll 1
-    for (int mi = wave; mi < IN / 32; mi += NW) {
+    for (int unit = wave; unit < (IN / 32) * RT; unit += NW) {
+        const int mi = unit / RT, rr = 32 * (unit % RT) + r;
         f32x16 acc = {0};
-        const float* a = W + 32 * mi + r;
-        const float* b = dz + r * DZ_STRIDE;
+        const float* a = W + 32 * mi;                // uniform
+        const unsigned al = (unsigned)(h * IN + r);  // this lane's element offset inside every k-step pair
+        const float* b = dz + rr * DZ_STRIDE;
+        // two register batches, as in dense_forward
+        float av0[32], av1[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) av0[u] = a[2 * u * IN + al];
 #pragma unroll 1
-        for (int s0 = 0; s0 < OUT / 2; s0 += 32) {
-            float av[32];
+        for (int s0 = 0; s0 < OUT / 2; s0 += 64) {
+            const bool more1 = s0 + 32 < OUT / 2, more2 = s0 + 64 < OUT / 2;
+            if (more1) {
 #pragma unroll
-            for (int u = 0; u < 32; ++u) av[u] = a[(2 * (s0 + u) + h) * IN];
+                for (int u = 0; u < 32; ++u) av1[u] = a[2 * (s0 + 32 + u) * IN + al];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 32; ++u) acc = mfma2(av[u], b[2 * (s0 + u) + h], acc);
+            for (int u = 0; u < 32; ++u) acc = mfma2(av0[u], b[2 * (s0 + u) + h], acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more2) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) av0[u] = a[2 * (s0 + 64 + u) * IN + al];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more1) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) acc = mfma2(av1[u], b[2 * (s0 + 32 + u) + h], acc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int in = 32 * mi + acc_feature(i, h);
-            dzin[r * IN_STRIDE + in] = acc[i] * dfactor(hin[r * IN_STRIDE + in], scale);
+            dzin[rr * IN_STRIDE + in] = acc[i] * dfactor(hin[rr * IN_STRIDE + in], scale);
         }
     }
 }

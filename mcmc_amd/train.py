@@ -46,7 +46,10 @@ class EnsembleTrainer:
     ``step`` is one pass of bayesian_ensemble.py:165-181 for every member on its own mini-batch.
     Pair index = member * num_samples + sample keys the Philox noise / mask streams."""
 
-    ACT_MAX_ROWS = 128  # batches up to this many rows save their activations for the backward kernel (else: recompute)
+    # The forward kernel's activations are kept for the backward kernel (autograd's saved tensors) while they fit this many
+    # bytes: 1.8 KB per pair and row - 2.9 MB at the reference's 50 pairs x 32 rows, 9.5 GB at 80 pairs x 65,536 rows.
+    # Larger batches recompute the forward tile in the backward kernel (the same numbers, ~1.2x the step time).
+    ACT_MAX_BYTES = 16 << 30
 
     def __init__(self, mu: torch.Tensor, rho: torch.Tensor, input_dim: int, num_samples: int = 10, *, p_drop: float = 0.1,
                  weight_decay: float = 0.01, beta2: float = 0.999, adam_eps: float = 1e-8, max_norm: float = 1.0,
@@ -96,8 +99,10 @@ class EnsembleTrainer:
             self._Y = self._Ybuf[:pairs * rows].view(pairs, rows)
             self._delta = self._dbuf[:self.M * rows].view(self.M, rows)
         # saved activations for the backward kernel of small batches (the reference's 32 rows: 2.9 MB for 50 pairs)
-        need = pairs * int(self.eng.lib.mcmc_train_act_floats(rows)) if rows <= self.ACT_MAX_ROWS else 0
-        if need and (self._act is None or self._act.numel() < need):
+        need = pairs * int(self.eng.lib.mcmc_train_act_floats(rows))
+        self._save_act = 4 * need <= self.ACT_MAX_BYTES
+        if self._save_act and (self._act is None or self._act.numel() < need):
+            self._act = None  # release before growing
             self._act = torch.empty(need, dtype=torch.float32, device=self.eng.device)
         return self._Y, self._delta
 
@@ -178,18 +183,28 @@ class EnsembleTrainer:
             xb, yb = xb.contiguous(), yb.contiguous()
         _lib.check(lib.mcmc_train_sample(h, _p(self.mu), _p(self.sigma), M, S, F, noise_mode, _p(eps), seed & _U64, _p(self.eps),
                                          _p(self.W), _p(self.WT), st), "mcmc_train_sample")
-        _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed, self.p_drop,
-                                          _p(Y), st), "mcmc_train_forward")
+        nb = int(lib.mcmc_train_row_blocks(rows))  # > 1 for large batches: each pair's rows run on nb workgroups
+        save = self._save_act  # the forward pass keeps its activations for the backward kernel (else: recomputed there)
+        if save:
+            _lib.check(lib.mcmc_train_forward_save(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
+                                                   self.p_drop, _p(Y), _p(self._act), st), "mcmc_train_forward_save")
+        else:
+            _lib.check(lib.mcmc_train_forward(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed, self.p_drop,
+                                              _p(Y), st), "mcmc_train_forward")
         if dp or rows >= 4096:  # large batches: the grid-wide piece-3 kernels instead of one workgroup per member
             self._dp_loss(Y, yb, rows, delta, group if dp else False, global_rows if dp else rows)
         else:
             _lib.check(lib.mcmc_train_loss(h, _p(Y), _p(yb), M, S, rows, self.alpha, self.beta, _p(delta), _p(self.loss), st),
                        "mcmc_train_loss")
-        nb = int(lib.mcmc_train_row_blocks(rows))  # > 1 for large batches: each pair's rows run on nb workgroups
         if self.dW.shape[0] < M * S * nb:
             self.dW = torch.empty(M * S * nb, self.P, dtype=torch.float32, device=self.eng.device)
-        _lib.check(lib.mcmc_train_backward_blocks(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2),
-                                                  mseed, self.p_drop, _p(delta), nb, _p(self.dW), st), "mcmc_train_backward_blocks")
+        if save:
+            _lib.check(lib.mcmc_train_backward_saved(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2),
+                                                     mseed, self.p_drop, _p(delta), nb, _p(self.dW), _p(self._act), st),
+                       "mcmc_train_backward_saved")
+        else:
+            _lib.check(lib.mcmc_train_backward_blocks(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2),
+                                                      mseed, self.p_drop, _p(delta), nb, _p(self.dW), st), "mcmc_train_backward_blocks")
         if update and (dp or nb > 1):
             self.t += 1
             _lib.check(lib.mcmc_train_grad(h, M, S, nb, F, _p(self.eps), _p(self.sigma), _p(self.dW), _p(self.gmu), _p(self.grho),

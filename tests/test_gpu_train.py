@@ -98,6 +98,26 @@ def test_train_step_matches_oracle(F, rows, S):
         np.testing.assert_allclose(tr.sigma.cpu().numpy(), np.exp(tr.rho.cpu().numpy()), rtol=2e-6)
 
 
+@pytest.mark.parametrize("rows", [96, 2500, 8192])
+def test_saved_activations_equal_recompute(rows):
+    """A step whose backward kernel reloads the forward pass's activations (the default while they fit ACT_MAX_BYTES) ==
+    the step whose backward kernel recomputes the forward tile: loss, gradients and parameters, bit for bit, at one
+    row block (32-row tiles, the one-call step) and at several (64-row tiles), Philox noise and masks live."""
+    from mcmc_amd.train import EnsembleTrainer
+    F, M, S = 11, 2, 3
+    mu, rho = _members(F, M, 3)
+    xb, yb = _batch(M, rows, F, 77)
+    out = []
+    for max_bytes in (EnsembleTrainer.ACT_MAX_BYTES, 0):
+        tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+        tr.ACT_MAX_BYTES = max_bytes
+        losses = [tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, seed=5 + it).clone() for it in range(2)]
+        assert tr._save_act == (max_bytes > 0)
+        out.append((torch.stack(losses), tr.gmu.clone(), tr.grho.clone(), tr.mu.clone(), tr.rho.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 def test_train_replays_reference_trajectory(golden):
     """Both golden members stepped together with the eps / masks / lr / beta1 the reference used."""
     from mcmc_amd.train import EnsembleTrainer
