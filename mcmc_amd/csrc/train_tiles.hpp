@@ -19,7 +19,8 @@ constexpr int kLdsFloats = TR * (SX + S1 + S2 + S3 + 1);  // 62 KB at 32 rows: t
 // h1, h2, h3 of one tile are contiguous in LDS: the forward kernel can save them (57.7 KB per pair and tile) so that
 // the backward kernel of a small batch reloads them from L2 instead of recomputing the tile's forward pass
 constexpr int kActFloats = TR * (S1 + S2 + S3);
-static_assert(kActFloats % 4 == 0 && (TR * SX) % 4 == 0, "activation tiles are copied as float4");
+constexpr int kActEarlyFloats = (H3 / 32) * RT < NW ? TR * (S1 + S2) : 0;  // h1 | h2: saved during layer 2 by its idle waves (forward_tile)
+static_assert(kActFloats % 4 == 0 && (TR * SX) % 4 == 0 && kActEarlyFloats % 4 == 0, "activation tiles are copied as float4");
 
 __device__ __forceinline__ Lds carve(float* base) {
     Lds l;
@@ -195,7 +196,7 @@ __device__ __forceinline__ void input_grad(const float* __restrict__ dz, const f
 // forward of one 32-row tile of one pair; fills xs, h1, h2, h3, y
 template <int MODE>
 __device__ __forceinline__ void forward_tile(const Lds& l, const float* __restrict__ xb, int64_t rows, int F, int64_t row_base,
-                                             const float* __restrict__ WT, const DropMask& dm, int pair) {
+                                             const float* __restrict__ WT, const DropMask& dm, int pair, float* __restrict__ act_tile = nullptr) {
     for (int i = threadIdx.x; i < TR * SX; i += NT) {
         const int r = i / SX, k = i % SX;
         l.xs[i] = (row_base + r < rows && k < F) ? xb[(row_base + r) * F + k] : 0.0f;
@@ -207,6 +208,14 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const float* __restri
     dense_forward<MODE, H2, S1, S2>(l.h1, H1, WT + flat_w_off(F, 1), WT + flat_b_off(F, 1), l.h2, dm, pair, rows, row_base, 1);
     __syncthreads();
     dense_forward<MODE, H3, S2, S3>(l.h2, H2, WT + flat_w_off(F, 2), WT + flat_b_off(F, 2), l.h3, dm, pair, rows, row_base, 2);
+    // Saving h1 and h2 for the backward kernel is the job of the waves that have no output tile in layer 2: a wave's next
+    // load waits for its earlier stores to be acknowledged (one counter for both), and these waves have no next load.
+    constexpr int kBusy = (H3 / 32) * RT < NW ? (H3 / 32) * RT : NW;
+    if (act_tile && kBusy < NW && (int)threadIdx.x >= kBusy * 64) {
+        float4* dst = reinterpret_cast<float4*>(act_tile);
+        const float4* src = reinterpret_cast<const float4*>(l.h1);
+        for (int i = threadIdx.x - kBusy * 64; i < kActEarlyFloats / 4; i += NT - kBusy * 64) dst[i] = src[i];
+    }
     __syncthreads();
     if (threadIdx.x < 8 * TR) {  // layer 3: 64 -> 1; 8 threads per row
         const int r = threadIdx.x >> 3, part = threadIdx.x & 7;
@@ -235,13 +244,14 @@ __global__ __launch_bounds__(NT, kWgPerCu) void train_forward_kernel(const float
     const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
     const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair);
+        const int64_t tiles = (rows + TR - 1) / TR;
+        float* act_tile = act ? act + ((int64_t)pair * tiles + row_base / TR) * kActFloats : nullptr;
+        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair, act_tile);
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
-        if (act) {  // keep the tile's activations for the backward kernel
-            const int64_t tiles = (rows + TR - 1) / TR;
-            float4* dst = reinterpret_cast<float4*>(act + ((int64_t)pair * tiles + row_base / TR) * kActFloats);
+        if (act) {  // keep the rest of the tile's activations (h3; forward_tile saved h1 and h2) for the backward kernel
+            float4* dst = reinterpret_cast<float4*>(act_tile);
             const float4* src = reinterpret_cast<const float4*>(l.h1);
-            for (int i = threadIdx.x; i < kActFloats / 4; i += NT) dst[i] = src[i];
+            for (int i = kActEarlyFloats / 4 + threadIdx.x; i < kActFloats / 4; i += NT) dst[i] = src[i];
         }
         __syncthreads();
     }
