@@ -19,6 +19,7 @@
 // for the forward) so every global access is lane-contiguous.  fp32 VALU arithmetic: windows are
 // 30 x 64, the step is launch/latency bound.
 #include "common.hpp"
+#include "elu.hpp"
 #include "member_loss.hpp"
 #include "philox.hpp"
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
-__device__ __forceinline__ float elu(float z) { return z > 0.0f ? z : expm1f(z); }
+__device__ __forceinline__ float elu(float z) { return z > 0.0f ? z : elu_neg(z); }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.0f / (1.0f + expf(-z)); }
 // derivative factor of a stored ELU(+dropout) activation; masked elements are stored as -0.0f
 __device__ __forceinline__ float dfactor(float h, float scale) {

@@ -16,6 +16,7 @@
 // within 2e-5 of the reference's fp32 autograd.
 #include "common.hpp"
 #include "dropmask.hpp"
+#include "elu.hpp"
 #include "member_loss.hpp"
 
 namespace mcmc {
@@ -31,15 +32,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // One k-step of v_mfma_f32_32x32x2_f32 (exact fp32 FMAs): D[32 x 32] += A[32 x 2] * B[2 x 32]; lane (r, h) feeds
 // A[r][h] and B[h][r]; afterwards register i of lane (r, h) holds D[acc_feature(i, h)][r] (layout.hpp).
 __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
-
-// expm1 for the ELU's negative branch: exp(z) - 1 where that keeps its relative accuracy (|z| >= 1/16: within 1e-6 of expm1),
-// the degree-4 Taylor polynomial below it (truncation z^4/120 < 1.3e-7 relative).  One v_exp_f32 and six FMAs / selects per
-// element; Kahan's (u - 1) * z / log(u) form used before (2 ulp) cost three transcendentals and ~20 % of the large-batch forward pass.
-__device__ __forceinline__ float elu_neg(float z) {
-    const float big = __expf(z) - 1.0f;
-    const float small = z * fmaf(z, fmaf(z, fmaf(z, 1.0f / 24.0f, 1.0f / 6.0f), 0.5f), 1.0f);
-    return z > -0.0625f ? small : big;
-}
 
 // derivative factor d = elu'(z) * mask * scale recovered from the stored activation
 __device__ __forceinline__ float dfactor(float h, float scale) {
