@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU session of round 2: [tests,] bench, rocprofv3 kernel stats of the bench, PMC passes of the forward and the reduce
-# kernels (one rocprofv3 run per counter set, no trace domains), kernel stats of the loss.  Digest: tools/profile_digest.py.
+# kernels (one rocprofv3 run per counter set, no trace domains), kernel stats of the loss, timings and kernel stats of the training / TFT steps.  Digest: tools/profile_digest.py.
 # usage: tools/gpu_round2.sh [notests|pmconly]
-set -u
+set -u -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/round2
 if [ "${1:-}" = "pmconly" ]; then
@@ -17,6 +17,13 @@ timeout -k 10 400 python -u bench.py > $out/bench.json 2> $out/bench.err || { ec
 cat $out/bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/prof.log 2>&1 || { echo PROF FAILED; tail -5 $out/prof.log; exit 1; }
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_loss -- python3 tools/bench_loss.py > $out/prof_loss.log 2>&1 || { echo LOSS PROF FAILED; tail -5 $out/prof_loss.log; exit 1; }
+# widened rows: training step (reference batch size and config-5 size), TFT step
+: > $out/train.jsonl
+for cmd in "tools/bench_train.py" "tools/bench_config5.py --rows 65536" "tools/bench_config5.py --rows 1048576" "tools/exp_train_act.py" "tools/bench_tft.py"; do
+  timeout -k 10 200 python3 $cmd 2> $out/train.err | tail -1 >> $out/train.jsonl || { echo "TRAIN BENCH FAILED: $cmd"; tail -5 $out/train.err; exit 1; }
+done
+cat $out/train.jsonl
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -- python3 tools/bench_config5.py --rows 65536 > $out/prof_train.log 2>&1 || { echo TRAIN PROF FAILED; tail -5 $out/prof_train.log; exit 1; }
 fi
 mkdir -p $out/pmc_fwd $out/pmc_red
 pmc() {  # pmc <dir> <counters...> -- <program args...>

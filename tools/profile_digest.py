@@ -6,6 +6,8 @@
   <tag>_bench.json                 the bench line
   <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of bench.py (steps 2, warmup 1)
   <tag>_loss_kernel_stats.csv      the same for tools/bench_loss.py
+  <tag>_train_kernel_stats.csv     the same for tools/bench_config5.py --rows 65536 (large-batch training step)
+  <tag>_train.jsonl                one line each: bench_train (32-row step), bench_config5 at 65,536 and 1,048,576 rows, exp_train_act, bench_tft
   <tag>_pmc_forward.csv / .json    PMC passes over tools/bench_forward.py (--dtype bf16_fast, 3.65 M rows x 256 pairs)
   <tag>_pmc_reduce.csv / .json     PMC passes over tools/bench_reduce.py (262,144 rows x 8,192 pairs: a bench row block)
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md)."""
@@ -71,6 +73,9 @@ def main():
         shutil.copy(os.path.join(src, "bench.json"), os.path.join(prof, f"{tag}_bench.json"))
     stats_csv(os.path.join(src, "prof"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
     stats_csv(os.path.join(src, "prof_loss"), os.path.join(prof, f"{tag}_loss_kernel_stats.csv"))
+    stats_csv(os.path.join(src, "prof_train"), os.path.join(prof, f"{tag}_train_kernel_stats.csv"))
+    if os.path.exists(os.path.join(src, "train.jsonl")):
+        shutil.copy(os.path.join(src, "train.jsonl"), os.path.join(prof, f"{tag}_train.jsonl"))
     fwd = pmc(os.path.join(src, "pmc_fwd"), "forward_bf16")
     if fwd:
         write_pmc(fwd, os.path.join(prof, f"{tag}_pmc_forward.csv"))
