@@ -6,7 +6,7 @@ constexpr int NW = NT / 64;
 constexpr int kWgPerCu = NT <= 256 ? 2 : 1;
 constexpr int TR = MCMC_TRAIN_TR;  // rows per LDS tile: 32, or 64 = two MFMA row tiles per pass of the tile code (large batches)
 constexpr int RT = TR / 32;
-static_assert(TR % 32 == 0 && NT >= 8 * TR || TR == 32, "layer 3 gives a row eight threads");
+static_assert(TR % 32 == 0 && NT >= 8 * TR, "layer 3 gives a row eight threads");
 
 struct Lds {
     float* xs;   // [TR][SX]  input tile, columns >= F are zero
