@@ -193,19 +193,46 @@ __device__ __forceinline__ void input_grad(const float* __restrict__ dz, const f
     }
 }
 
-// forward of one 32-row tile of one pair; fills xs, h1, h2, h3, y
+// What the forward KERNEL carries from tile to tile so that a tile's critical path has no global load behind a store
+// (a wave's load waits for the acknowledgement of its earlier stores): the output layer's weights, read once per
+// workgroup, and the next tile's input rows, fetched under layer 1 of the current tile into the then-idle xs tile.
+struct TileCarry {
+    float w3[8];        // this thread's eight output-layer weights (thread = (row, part of 8))
+    float b3;
+    bool xs_ready;      // l.xs already holds this tile's rows (the previous tile prefetched them)
+    int64_t next_base;  // first row of the next tile to prefetch, or -1
+};
+
+__device__ __forceinline__ float xs_elem(const float* __restrict__ xb, int64_t rows, int F, int64_t row_base, int i) {
+    const int r = i / SX, k = i % SX;
+    return (row_base + r < rows && k < F) ? xb[(row_base + r) * F + k] : 0.0f;
+}
+
+// forward of one tile of one pair; fills xs, h1, h2, h3, y
 template <int MODE>
 __device__ __forceinline__ void forward_tile(const Lds& l, const float* __restrict__ xb, int64_t rows, int F, int64_t row_base,
-                                             const float* __restrict__ WT, const DropMask& dm, int pair, float* __restrict__ act_tile = nullptr) {
-    for (int i = threadIdx.x; i < TR * SX; i += NT) {
-        const int r = i / SX, k = i % SX;
-        l.xs[i] = (row_base + r < rows && k < F) ? xb[(row_base + r) * F + k] : 0.0f;
+                                             const float* __restrict__ WT, const DropMask& dm, int pair, float* __restrict__ act_tile = nullptr,
+                                             const TileCarry* carry = nullptr) {
+    constexpr int XN = (TR * SX + NT - 1) / NT;
+    if (!(carry && carry->xs_ready)) {
+        for (int i = threadIdx.x; i < TR * SX; i += NT) l.xs[i] = xs_elem(xb, rows, F, row_base, i);
+        __syncthreads();
     }
-    __syncthreads();
     // layer 0: k runs over the F real columns only (the next flat entry after W0^T is the bias, never read as a weight)
     dense_forward<MODE, H1, SX, S1>(l.xs, F, WT + flat_w_off(F, 0), WT + flat_b_off(F, 0), l.h1, dm, pair, rows, row_base, 0);
     __syncthreads();
+    const bool prefetch = carry && carry->next_base >= 0;
+    float xr[XN];
+    if (prefetch) {  // the xs tile is idle from here on (forward kernel only): the loads land under layer 1
+#pragma unroll
+        for (int q = 0; q < XN; ++q) xr[q] = threadIdx.x + q * NT < TR * SX ? xs_elem(xb, rows, F, carry->next_base, threadIdx.x + q * NT) : 0.0f;
+    }
     dense_forward<MODE, H2, S1, S2>(l.h1, H1, WT + flat_w_off(F, 1), WT + flat_b_off(F, 1), l.h2, dm, pair, rows, row_base, 1);
+    if (prefetch) {
+#pragma unroll
+        for (int q = 0; q < XN; ++q)
+            if (threadIdx.x + q * NT < TR * SX) l.xs[threadIdx.x + q * NT] = xr[q];
+    }
     __syncthreads();
     dense_forward<MODE, H3, S2, S3>(l.h2, H2, WT + flat_w_off(F, 2), WT + flat_b_off(F, 2), l.h3, dm, pair, rows, row_base, 2);
     // Saving h1 and h2 for the backward kernel is the job of the waves that have no output tile in layer 2: a wave's next
@@ -222,11 +249,11 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const float* __restri
         const float* w3 = WT + flat_w_off(F, 3);
         float a = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a = fmaf(l.h3[r * S3 + part * 8 + k], w3[part * 8 + k], a);
+        for (int k = 0; k < 8; ++k) a = fmaf(l.h3[r * S3 + part * 8 + k], carry ? carry->w3[k] : w3[part * 8 + k], a);
         a += __shfl_xor(a, 1);
         a += __shfl_xor(a, 2);
         a += __shfl_xor(a, 4);
-        if (part == 0) l.y[r] = a + WT[flat_b_off(F, 3)];
+        if (part == 0) l.y[r] = a + (carry ? carry->b3 : WT[flat_b_off(F, 3)]);
     }
     __syncthreads();
 }
@@ -243,10 +270,20 @@ __global__ __launch_bounds__(NT, kWgPerCu) void train_forward_kernel(const float
     // rows of a large batch are split over blockIdx.y in runs of whole tiles
     const int64_t per = (((rows + gridDim.y - 1) / gridDim.y) + TR - 1) / TR * TR;
     const int64_t begin = (int64_t)blockIdx.y * per, end = begin + per < rows ? begin + per : rows;
+    TileCarry carry;
+    {
+        const float* w3 = WT + (int64_t)pair * P + flat_w_off(F, 3);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) carry.w3[k] = w3[(threadIdx.x & 7) * 8 + k];
+        carry.b3 = WT[(int64_t)pair * P + flat_b_off(F, 3)];
+        carry.xs_ready = false;
+    }
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         const int64_t tiles = (rows + TR - 1) / TR;
         float* act_tile = act ? act + ((int64_t)pair * tiles + row_base / TR) * kActFloats : nullptr;
-        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair, act_tile);
+        carry.next_base = row_base + TR < end ? row_base + TR : -1;
+        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, WT + (int64_t)pair * P, dm, pair, act_tile, &carry);
+        carry.xs_ready = carry.next_base >= 0;
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
         if (act) {  // keep the rest of the tile's activations (h3; forward_tile saved h1 and h2) for the backward kernel
             float4* dst = reinterpret_cast<float4*>(act_tile);
