@@ -161,19 +161,23 @@ def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
-def combine_partials(state: ReduceState, group=None) -> ReduceState:
+def combine_partials(state: ReduceState, group=None, n_total: Optional[int] = None) -> ReduceState:
     """Sum-combine the partials of all ranks: fp64 moments and the histogram
     (uint16 pairs viewed as int32: no carry crosses a half while total counts stay <= 65,535).
-    RCCL over xGMI when the tensors are on GPUs (backend 'nccl'), gloo on CPU tensors in tests."""
+    RCCL over xGMI when the tensors are on GPUs (backend 'nccl'), gloo on CPU tensors in tests.
+    ``n_total``: the combined sample count when the caller knows it (mc_predict does: the shards are a pure function of
+    rank and world) - saves the count's all-reduce and the host sync that reading it costs."""
     import torch.distributed as dist
     if _single_process(group):
         return state
     moments = torch.stack([state.sum, state.sumsq])
-    count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
     all_reduce_sum(moments, group)
-    all_reduce_sum(count, group)
     state.sum, state.sumsq = moments[0].contiguous(), moments[1].contiguous()
-    state.n = int(count.item())
+    if n_total is None:
+        count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
+        all_reduce_sum(count, group)
+        n_total = int(count.item())
+    state.n = int(n_total)
     if state.hist is not None:
         if state.n > 65535:
             raise ValueError(f"uint16 histogram holds at most 65,535 samples per row (n = {state.n})")
@@ -187,7 +191,7 @@ def row_slice(B: int, rank: int, world: int) -> Tuple[int, int, int]:
     return min(rank * per, B), min((rank + 1) * per, B), per
 
 
-def scatter_combine(state: ReduceState, group=None, merge=None) -> Tuple[ReduceState, int, int]:
+def scatter_combine(state: ReduceState, group=None, merge=None, n_total: Optional[int] = None) -> Tuple[ReduceState, int, int]:
     """Reduce-scatter over rows: every rank ends up with the fully combined partials
     of its own row slice only.  Built on all_to_all_single of raw bytes + ``merge`` (Engine.reduce_merge =
     mcmc_reduce_merge: the sum of the world's slices in rank order, in the library): the same wire traffic as
@@ -221,9 +225,11 @@ def scatter_combine(state: ReduceState, group=None, merge=None) -> Tuple[ReduceS
             out = out.to(t.device)
         return out.view(t.dtype).view((world, mine) + tuple(t.shape[1:]))
 
-    count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
-    all_reduce_sum(count, group)
-    n = int(count.item())
+    if n_total is None:  # the combined sample count, unless the caller knows it (see combine_partials)
+        count = torch.tensor([state.n], dtype=torch.int64, device=state.sum.device)
+        all_reduce_sum(count, group)
+        n_total = int(count.item())
+    n = int(n_total)
     if state.hist is not None and n > 65535:
         raise ValueError(f"uint16 histogram holds at most 65,535 samples per row (n = {n})")
     s1, s2, hist = merge(exchange(state.sum), exchange(state.sumsq), exchange(state.hist) if state.hist is not None else None, state.nbins)
@@ -523,6 +529,12 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
         # pilot pairs q < n_pilot, whichever ranks own them; bounded by the pair chunk only when pairs ARE chunked, so that
         # they sit in every owner's first chunk and the choice does not depend on the world size
         n_pilot = min(pilot_pairs(N, M), Cplan if Cplan < n_max else N)
+        # what the ranks' pilot contributions add up to (each owner gives the pilot pairs of its FIRST chunk): known on
+        # every rank without asking, so the pilot combine needs no count exchange and no host sync
+        n_pilot_total = 0
+        for r in range(world):
+            b_r, e_r = shard_pairs(N, r, world, shard_weights if world > 1 else None)
+            n_pilot_total += max(0, min(min(Cplan, e_r - b_r), n_pilot - b_r))
         ldY = (min(Rb, B) + 63) // 64 * 64
         Y = torch.empty(Cn, ldY, dtype=torch.float32, device=eng.device)
         wpack = torch.empty(Cn * wbytes, dtype=torch.uint8, device=eng.device)
@@ -563,7 +575,7 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                         mine = max(0, min(cnt, n_pilot - begin))
                         if mine:
                             eng.reduce_update(Y, ldY, mine, rb, pblk)
-                        pblk = combine_partials(pblk, group)
+                        pblk = combine_partials(pblk, group, n_total=n_pilot_total)
                         eng.set_edges(rb, max(pblk.n, 1), pblk.sum, pblk.sumsq, blk, range_sigmas)
                 first = False
                 with _timed(timers, "reduce_update", cnt * rb):
@@ -571,14 +583,14 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                 if samples is not None:
                     samples[pair_global_ids(begin, cnt, M, S, eng.device), r0:r0 + rb] = Y[:cnt, :rb]
             if nq and first:  # a rank without pairs still joins the block's pilot combine
-                pblk = combine_partials(ReduceState(0, rows_of(pilot.sum, r0, rb), rows_of(pilot.sumsq, r0, rb)), group)
+                pblk = combine_partials(ReduceState(0, rows_of(pilot.sum, r0, rb), rows_of(pilot.sumsq, r0, rb)), group, n_total=n_pilot_total)
                 eng.set_edges(rb, max(pblk.n, 1), pblk.sum, pblk.sumsq, blk, range_sigmas)
         st.n = n_local
 
         width = (1.0 / st.inv_w) if nq else None
         # exchange step: reduce-scatter over rows -> finalize the own slice -> all-gather the results
         with _timed(timers, "exchange"):
-            part, r0, r1 = scatter_combine(st, group, eng.reduce_merge)
+            part, r0, r1 = scatter_combine(st, group, eng.reduce_merge, n_total=N)
         with _timed(timers, "finalize"):
             mean, std, quant = eng.finalize(r1 - r0, part, q_levels)
         with _timed(timers, "gather"):
