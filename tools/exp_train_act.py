@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--mask-mode", type=int, default=2, help="0: no dropout, 2: Philox masks")
+    ap.add_argument("--variants", default="recompute,saved", help="which backward forms to run (PMC passes: one)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     M, S, F, R = 8, 10, 11, args.rows
@@ -55,7 +56,7 @@ def main():
         assert bwd(_p(xb), R * F, R, F, M, S, _p(tr.W), _p(tr.WT), args.mask_mode, None, None, None, 7, 0.1, _p(delta), nb, _p(dW), _p(a), None, _stream()) == 0
 
     ref = None
-    for name, a in (("recompute", None), ("saved", act)):
+    for name, a in [(n, {"recompute": None, "saved": act}[n]) for n in args.variants.split(",")]:
         run(a)
         torch.cuda.synchronize()
         if ref is None:

@@ -41,4 +41,5 @@ pmc $out/pmc_red/pass1 FETCH_SIZE -- $R || exit 1
 pmc $out/pmc_red/pass2 WRITE_SIZE -- $R || exit 1
 pmc $out/pmc_red/pass3 GRBM_GUI_ACTIVE GRBM_COUNT -- $R || exit 1
 pmc $out/pmc_red/pass4 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -- $R || exit 1
+bash tools/pmc_train.sh $out/pmc_train > $out/pmc_train.log 2>&1 || { echo "pmc_train failed"; tail -5 $out/pmc_train.log; exit 1; }
 echo ROUND2 OK
