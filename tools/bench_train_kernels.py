@@ -1,12 +1,11 @@
 #!/usr/bin/env python3
-"""Experiment: large-batch training step with the forward pass's activations SAVED to HBM and reloaded by the backward kernel
-(what the 32-row step does through L2) instead of recomputed.  Calls the library's internal launchers by their mangled
-names - a measurement aid, not an interface.
+"""Large-batch training kernels alone: forward / backward of 80 pairs x 65,536 rows, with the forward pass's activations
+recomputed by the backward kernel (mcmc_train_forward / mcmc_train_backward_blocks) or saved and reloaded
+(mcmc_train_forward_save / mcmc_train_backward_saved).  Timing and PMC target (tools/pmc_train.sh).
 
-    python tools/exp_train_act.py [--rows 65536]
+    python tools/bench_train_kernels.py [--rows 65536]
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -14,11 +13,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mcmc_amd import _lib  # noqa: E402
 from mcmc_amd.engine import _p, _stream, param_count  # noqa: E402
 from mcmc_amd.train import EnsembleTrainer  # noqa: E402
 
-FWD = "_ZN4mcmc20launch_train_forwardEPKflliiiS1_iPKhS3_S3_mfPfS4_P12ihipStream_t"
-BWD = "_ZN4mcmc21launch_train_backwardEPKflliiiS1_S1_iPKhS3_S3_mfS1_iPfS1_PKNS_13TrainLossFuseEP12ihipStream_t"
 
 
 def main():
@@ -39,11 +37,7 @@ def main():
     tr = EnsembleTrainer(mu, rho, F, S)
     tr.step(xb, yb, 1e-3, 0.9, seed=1, update=False)  # fills W / WT and sizes the buffers
     lib = tr.eng.lib
-    fwd, bwd = getattr(lib, FWD), getattr(lib, BWD)
-    vp, i64, i32, u64, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_float
-    fwd.argtypes = [vp, i64, i64, i32, i32, i32, vp, i32, vp, vp, vp, u64, f32, vp, vp, vp]
-    bwd.argtypes = [vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, vp, u64, f32, vp, i32, vp, vp, vp, vp]
-    fwd.restype = bwd.restype = i32
+    h = tr.eng.ctx.handle
     nb = int(lib.mcmc_train_row_blocks(R))
     Y = torch.empty(M * S, R, device=dev)
     delta = torch.randn(M, R, device=dev, generator=gr) * 1e-4
@@ -51,9 +45,25 @@ def main():
     act = torch.empty(M * S * int(lib.mcmc_train_act_floats(R)), device=dev)
     out = {"mask_mode": args.mask_mode, "rows": R, "row_blocks": nb, "act_GB": act.numel() * 4 / 1e9}
 
+    mm = args.mask_mode
+
+    def forward(a):
+        if a is None:
+            _lib.check(lib.mcmc_train_forward(h, _p(xb), R, F, M, S, _p(tr.WT), mm, None, None, None, 7, 0.1, _p(Y), _stream()), "forward")
+        else:
+            _lib.check(lib.mcmc_train_forward_save(h, _p(xb), R, F, M, S, _p(tr.WT), mm, None, None, None, 7, 0.1, _p(Y), _p(a), _stream()), "forward_save")
+
+    def backward(a):
+        if a is None:
+            _lib.check(lib.mcmc_train_backward_blocks(h, _p(xb), R, F, M, S, _p(tr.W), _p(tr.WT), mm, None, None, None, 7, 0.1, _p(delta), nb,
+                                                      _p(dW), _stream()), "backward_blocks")
+        else:
+            _lib.check(lib.mcmc_train_backward_saved(h, _p(xb), R, F, M, S, _p(tr.W), _p(tr.WT), mm, None, None, None, 7, 0.1, _p(delta), nb,
+                                                     _p(dW), _p(a), _stream()), "backward_saved")
+
     def run(a):
-        assert fwd(_p(xb), R * F, R, F, M, S, _p(tr.WT), args.mask_mode, None, None, None, 7, 0.1, _p(Y), _p(a), _stream()) == 0
-        assert bwd(_p(xb), R * F, R, F, M, S, _p(tr.W), _p(tr.WT), args.mask_mode, None, None, None, 7, 0.1, _p(delta), nb, _p(dW), _p(a), None, _stream()) == 0
+        forward(a)
+        backward(a)
 
     ref = None
     for name, a in [(n, {"recompute": None, "saved": act}[n]) for n in args.variants.split(",")]:
@@ -65,9 +75,9 @@ def main():
             out["dW_equal"] = bool(torch.equal(ref, dW))
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
-        assert fwd(_p(xb), R * F, R, F, M, S, _p(tr.WT), args.mask_mode, None, None, None, 7, 0.1, _p(Y), _p(a), _stream()) == 0
+        forward(a)
         ev[1].record()
-        assert bwd(_p(xb), R * F, R, F, M, S, _p(tr.W), _p(tr.WT), args.mask_mode, None, None, None, 7, 0.1, _p(delta), nb, _p(dW), _p(a), None, _stream()) == 0
+        backward(a)
         ev[2].record()
         torch.cuda.synchronize()
         out[name] = {"forward_ms": ev[0].elapsed_time(ev[1]), "backward_ms": ev[1].elapsed_time(ev[2])}

@@ -1,7 +1,7 @@
 #!/bin/bash
-# PMC passes over the large-batch training kernels (tools/exp_train_act.py --variants saved: forward / backward at 65,536 rows x 80 pairs
+# PMC passes over the large-batch training kernels (tools/bench_train_kernels.py --variants saved: forward / backward at 65,536 rows x 80 pairs
 # with saved activations): where the waves' cycles go.  Separate rocprofv3 runs per counter set, no trace domains.
-# usage: tools/pmc_train.sh <outdir> [exp_train_act args...]
+# usage: tools/pmc_train.sh <outdir> [bench_train_kernels args...]
 set -u
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -12,6 +12,6 @@ for set in \
   "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" \
   "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_SMEM" ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 tools/exp_train_act.py --variants saved "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 tools/bench_train_kernels.py --variants saved "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; exit 1; }
 done
 echo done

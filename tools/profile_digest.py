@@ -7,9 +7,9 @@
   <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of bench.py (steps 2, warmup 1)
   <tag>_loss_kernel_stats.csv      the same for tools/bench_loss.py
   <tag>_train_kernel_stats.csv     the same for tools/bench_config5.py --rows 65536 (large-batch training step)
-  <tag>_train.jsonl                one line each: bench_train (32-row step), bench_config5 at 65,536 and 1,048,576 rows, exp_train_act, bench_tft
+  <tag>_train.jsonl                one line each: bench_train (32-row step), bench_config5 at 65,536 and 1,048,576 rows, bench_train_kernels, bench_tft
   <tag>_pmc_forward.csv / .json    PMC passes over tools/bench_forward.py (--dtype bf16_fast, 3.65 M rows x 256 pairs)
-  <tag>_pmc_train.csv              PMC passes over tools/exp_train_act.py (65,536 rows x 80 pairs: forward / backward, recomputing and saved)
+  <tag>_pmc_train.csv              PMC passes over tools/bench_train_kernels.py (65,536 rows x 80 pairs: forward / backward, recomputing and saved)
   <tag>_pmc_reduce.csv / .json     PMC passes over tools/bench_reduce.py (262,144 rows x 8,192 pairs: a bench row block)
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md)."""
 import csv
