@@ -41,6 +41,12 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWaves = 8;  // per workgroup = per CU: the weight image admits one workgroup per CU
+#ifdef MCMC_FWD_STAMP
+// Diagnostic build only (tools/fwd_ablate.hip -DMCMC_FWD_STAMP; never defined for the library): every workgroup stamps
+// s_memtime / s_memrealtime once around its tile loop into this array, which nothing else reads - the in-kernel clock is
+// d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long g_fwd_stamp[2 * 65536];
+#endif
 constexpr int kTiles = 2;  // 32-row tiles per wave
 
 // bits(c * 2^a) ~ 128 * (a + log2(c) + 127) + kFieldShift,  a = u - c;  as the fraction of 65535 that
@@ -258,6 +264,10 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_fast_ker
     int64_t blk_end = blk_begin + rows_per_block;
     if (blk_end > padded) blk_end = padded;
 
+#ifdef MCMC_FWD_STAMP
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) alone
+#endif
     for (int64_t row0 = blk_begin + 32 * T * wave; row0 < blk_end; row0 += 32 * T * kWaves) {
         // the weight image is loop-invariant: without this the compiler hoists the A fragments
         // (352 VGPRs) out of the tile loop and spills
@@ -348,6 +358,13 @@ __global__ __launch_bounds__(64 * kWaves, kWaves / 4) void forward_bf16_fast_ker
             if (h == 0 && row < n_rows && row0 + 32 * t < blk_end) Y[(int64_t)c * ldY + row] = acc3[t][0] + b3;
         }
     }
+#ifdef MCMC_FWD_STAMP
+    if (threadIdx.x == 0) {
+        const unsigned slot = (blockIdx.y * gridDim.x + blockIdx.x) & 65535u;
+        g_fwd_stamp[2 * slot] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        g_fwd_stamp[2 * slot + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    }
+#endif
 }
 
 template <typename LAYOUT, typename KERNEL, typename... EXTRA>

@@ -1,6 +1,8 @@
 // Dev tool: time the product's forward_bf16_kernel on random operands without torch (ablations: edit a copy of the kernel
 // source and build this harness against it with -DFWD_SRC='"path"').
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Imcmc_amd/csrc tools/fwd_ablate.hip -o build/fwd_ablate
+// With -DMCMC_FWD_STAMP (a diagnostic build: the fast kernel stamps s_memtime / s_memrealtime around its tile loop) and a
+// fifth argument N it also runs N launches back to back (>= 2 s) and prints the in-kernel clock of the last one.
 #ifndef FWD_SRC
 #define FWD_SRC "../mcmc_amd/csrc/forward_bf16.hip"
 #endif
@@ -8,6 +10,7 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 namespace mcmc {
@@ -67,6 +70,28 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, a, b));
         if (ms < best) best = ms;
     }
+#ifdef MCMC_FWD_STAMP
+    const int burst = argc > 5 ? atoi(argv[5]) : 80;
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < burst; ++i)
+        if (mcmc::launch_forward_bf16(nullptr, fast, dx, rows, F, dw, pairs, nullptr, dy, ldY, 0)) return 1;
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    {
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        std::vector<unsigned long long> st(2 * 65536);
+        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(mcmc::g_fwd_stamp), st.size() * 8));
+        std::vector<double> mhz;
+        for (int i = 0; i < 65536; ++i)
+            if (st[2 * i + 1]) mhz.push_back(100.0 * (double)st[2 * i] / (double)st[2 * i + 1]);
+        std::sort(mhz.begin(), mhz.end());
+        if (!mhz.empty())
+            printf("stamped build: %d launches back to back %.1f ms each (%.1f TFLOP/s alg); in-kernel clock median %.0f MHz (p10 %.0f, p90 %.0f; %zu workgroups)\n",
+                   burst, ms / burst, (double)rows * pairs * 87680.0 / (ms / burst) / 1e9, mhz[mhz.size() / 2], mhz[mhz.size() / 10],
+                   mhz[mhz.size() * 9 / 10], mhz.size());
+    }
+#endif
     const double units = (double)rows * pairs;
     printf("%s rows=%lld pairs=%d best %.3f ms  %.1f TFLOP/s(alg)\n", fast ? "fast " : "exact", (long long)rows, pairs, best, units * 87680.0 / best / 1e9);
     return 0;
