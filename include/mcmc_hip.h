@@ -116,12 +116,14 @@ int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, in
  * :158; an opt-in MC-dropout predict - the reference's predict() itself runs in eval mode): the
  * keep flag of hidden activation elem (0..447 over the three layers) of global pair id
  * g = (q % n_members) * n_samples + q / n_members, q = pair_begin + c, and batch row `row` is
- * u01(Philox4x32-10(counter (elem>>2, g, 'MASK', row), key mask_seed)[elem&3]) < 1 - p_drop:
- * the stream of mcmc_train_forward's mask_mode 2, so predict and train see the same masks. */
+ * u01(Philox4x32-10(counter (elem>>2, g, 'MASK', row_begin + row), key mask_seed)[elem&3]) < 1 - p_drop:
+ * the stream of mcmc_train_forward's mask_mode 2, so predict and train see the same masks.
+ * row_begin: global index of the launch's first row (0 unless the launch is one row block of a
+ * larger input: the masks then do not depend on how the rows are cut into launches). */
 int mcmc_forward_dropout(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows,
                          int input_dim, const void* wpack, int n_members, int n_samples,
                          int64_t pair_begin, int pair_count, uint64_t mask_seed, float p_drop,
-                         float* Y, int64_t ldY, mcmc_stream_t stream);
+                         int64_t row_begin, float* Y, int64_t ldY, mcmc_stream_t stream);
 
 /* ---- piece 2: streaming per-timestep statistics ------------------------------------------- */
 /* Replaces torch.stack + reshape + mean(0) + std(0) (bayesian_ensemble.py:234-246) without

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16, DT_BF16_FAST = 0, 1, 2
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class MCMCLibraryError(RuntimeError):
@@ -58,7 +58,7 @@ SIGNATURES = {
     "mcmc_sample_weights_seedptr": (_i32, [_ctx_p, _ptr, _ptr, _i32, _i32, _i32, _i64, _i32, _ptr, _i32, _ptr, _stream]),
     "mcmc_philox_eps": (_i32, [_ctx_p, _u64, _i64, _i32, _i32, _ptr, _stream]),
     "mcmc_forward": (_i32, [_ctx_p, _i32, _ptr, _i64, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _f32, _ptr, _i64, _stream]),
-    "mcmc_forward_dropout": (_i32, [_ctx_p, _i32, _ptr, _i64, _i32, _ptr, _i32, _i32, _i64, _i32, _u64, _f32, _ptr, _i64, _stream]),
+    "mcmc_forward_dropout": (_i32, [_ctx_p, _i32, _ptr, _i64, _i32, _ptr, _i32, _i32, _i64, _i32, _u64, _f32, _i64, _ptr, _i64, _stream]),
     "mcmc_reduce_update": (_i32, [_ctx_p, _ptr, _i64, _i32, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _stream]),
     "mcmc_reduce_merge": (_i32, [_ctx_p, _i32, _i64, _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _stream]),
     "mcmc_reduce_set_edges": (_i32, [_ctx_p, _i64, _i64, _ptr, _ptr, _i32, _f32, _ptr, _ptr, _stream]),

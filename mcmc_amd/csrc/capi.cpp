@@ -2,7 +2,10 @@
 // Declarations and the reference lines each one replaces: include/mcmc_hip.h.
 #include <string.h>
 
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 
 #include "common.hpp"
 #include "dropmask.hpp"
@@ -17,6 +20,21 @@ int set_error(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+int ensure_dyn_lds(const void* kern, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> granted;  // (kernel, device) -> largest limit set so far
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDevice: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = granted[{kern, dev}];
+    if (bytes <= have) return MCMC_OK;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(%s, %zu B LDS): %s", what, bytes, hipGetErrorString(e));
+    have = bytes;
+    return MCMC_OK;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -35,7 +53,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 18; }
+int mcmc_abi_version(void) { return 19; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -177,12 +195,14 @@ int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, in
 }
 
 int mcmc_forward_dropout(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, int input_dim, const void* wpack, int n_members,
-                         int n_samples, int64_t pair_begin, int pair_count, uint64_t mask_seed, float p_drop, float* Y, int64_t ldY,
-                         mcmc_stream_t stream) {
+                         int n_samples, int64_t pair_begin, int pair_count, uint64_t mask_seed, float p_drop, int64_t row_begin, float* Y,
+                         int64_t ldY, mcmc_stream_t stream) {
     MCMC_REQUIRE(n_members >= 1 && n_samples >= 1, "n_members and n_samples must be >= 1");
     MCMC_REQUIRE(pair_begin >= 0 && pair_count >= 0 && pair_begin + pair_count <= (int64_t)n_members * n_samples,
                  "pair range [%lld, +%d) outside n_members*n_samples", (long long)pair_begin, pair_count);
-    MCMC_REQUIRE((int64_t)n_members * n_samples <= 0x7FFFFFFFLL && n_rows <= 0xFFFFFFFFLL, "pair or row index exceeds the 32-bit Philox counter");
+    MCMC_REQUIRE(row_begin >= 0, "row_begin < 0");
+    MCMC_REQUIRE((int64_t)n_members * n_samples <= 0x7FFFFFFFLL && n_rows <= 0xFFFFFFFFLL && row_begin <= 0xFFFFFFFFLL - n_rows,
+                 "pair or row index exceeds the 32-bit Philox counter");
     MCMC_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "p_drop must be in [0, 1)");
     DropMask dm{};
     dm.seed = mask_seed;
@@ -192,6 +212,7 @@ int mcmc_forward_dropout(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_
     dm.M = n_members;
     dm.S = n_samples;
     dm.pair_begin = pair_begin;
+    dm.row_begin = row_begin;
     return forward_impl(ctx, dtype, xpack, n_rows, input_dim, wpack, pair_count, &dm, Y, ldY, stream);
 }
 

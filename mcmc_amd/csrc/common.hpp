@@ -31,6 +31,10 @@ inline int check_ctx(const mcmc_ctx* ctx) {
     return MCMC_OK;
 }
 
+// Raises a kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize: sticky per function and device) the first
+// time a (kernel, device) pair needs `bytes` or more, not on every launch; thread-safe.  capi.cpp.
+int ensure_dyn_lds(const void* kern, size_t bytes, const char* what);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_error(MCMC_EHIP, "%s: %s", what, hipGetErrorString(e));

@@ -20,6 +20,8 @@ struct DropMask {
     float scale;          // fp32(1/(1-p))
     int M, S;             // mode 2: processing index q = pair_begin + c -> global pair id (q % M) * S + q / M
     int64_t pair_begin;
+    int64_t row_begin;    // mode 2: global index of the launch's row 0 (a row block of a larger predict keys the masks of its
+                          // rows by their global index, so the masks do not depend on how the rows are cut into launches)
 };
 
 __device__ __forceinline__ uint32_t drop_pair_id(const DropMask& dm, int c) {
@@ -49,7 +51,7 @@ __device__ __forceinline__ void drop16(float (&o)[16], const DropMask& dm, int l
             // every Philox block of the fully unrolled network to the top of the tile and spills.
             uint32_t ctr0 = (uint32_t)(base + feat0) >> 2;
             asm volatile("" : "+v"(ctr0) : "v"(o[4 * q]));
-            const u32x4 x = philox4x32_10(u32x4{ctr0, g, kTagMask, (uint32_t)row}, (uint32_t)dm.seed, (uint32_t)(dm.seed >> 32));
+            const u32x4 x = philox4x32_10(u32x4{ctr0, g, kTagMask, (uint32_t)(dm.row_begin + row)}, (uint32_t)dm.seed, (uint32_t)(dm.seed >> 32));
             keep[0] = u01(x.x) < dm.keep_prob;
             keep[1] = u01(x.y) < dm.keep_prob;
             keep[2] = u01(x.z) < dm.keep_prob;

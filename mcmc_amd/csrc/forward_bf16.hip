@@ -372,8 +372,7 @@ static int launch_slabs(KERNEL kern, const void* xpack, int64_t n_rows, int F, c
                         hipStream_t s, DropMask dm, bool with_masks) {
     const LAYOUT L(F);
     const size_t lds_bytes = (size_t)L.total;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_bf16, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes, "forward_bf16")) return rc;
     // Row superblock: large enough that staging ~90 KB of weights is ~1 % of its MFMA time
     // (32 double tiles per wave), small enough that pairs x superblocks >> 256 CUs.
     const int64_t padded = rows_pad(n_rows);

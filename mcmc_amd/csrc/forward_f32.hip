@@ -129,8 +129,7 @@ int launch_forward_f32(const float* xpack, int64_t n_rows, int F, const float* w
     const size_t lds_bytes = (size_t)L.l2 * sizeof(float);
     const DropMask dm = dmp ? *dmp : DropMask{};
     auto kern = dm.mode == 1 ? forward_f32_kernel<1> : dm.mode == 2 ? forward_f32_kernel<2> : forward_f32_kernel<0>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(forward_f32, %zu B LDS): %s", lds_bytes, hipGetErrorString(e));
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds_bytes, "forward_f32")) return rc;
     const int64_t row_blocks = (rows_pad(n_rows) + kRowsF32 - 1) / kRowsF32;
     for (int done = 0; done < pair_count;) {
         const int n = pair_count - done > 32768 ? 32768 : pair_count - done;

@@ -449,9 +449,7 @@ int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n
         const size_t red_bytes = 2 * kWavesR * kRows * sizeof(double);
         if (hist) {
             const size_t lds = red_bytes + (size_t)kRows * (nbins / 2) * sizeof(uint32_t);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_update4_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(reduce_update4): %s", hipGetErrorString(e));
+            if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(reduce_update4_kernel<true>), lds, "reduce_update4")) return rc;
             hipLaunchKernelGGL(reduce_update4_kernel<true>, dim3((unsigned)blocks), dim3(kRows * kWavesR), lds, s, Y, ldY, n_pairs,
                                n_rows, sum, sumsq, lo, inv_w, reinterpret_cast<uint32_t*>(hist), nbins);
         } else {
@@ -464,9 +462,7 @@ int launch_reduce_update(const mcmc_ctx* ctx, const float* Y, int64_t ldY, int n
     const size_t red_bytes = 2 * kWavesR * kRows * sizeof(double);
     if (hist) {
         const size_t lds = red_bytes + (size_t)kRows * (nbins / 2) * sizeof(uint32_t);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_update_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(reduce_update): %s", hipGetErrorString(e));
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(reduce_update_kernel<true>), lds, "reduce_update")) return rc;
         hipLaunchKernelGGL(reduce_update_kernel<true>, dim3((unsigned)blocks), dim3(kRows * kWavesR), lds, s, Y, ldY, n_pairs,
                            n_rows, sum, sumsq, lo, inv_w, reinterpret_cast<uint32_t*>(hist), nbins);
     } else {

@@ -902,10 +902,7 @@ TftMasks make_masks(int mode, const uint8_t* g0, const uint8_t* g1, const uint8_
 
 template <typename K>
 int set_lds(K kernel, const char* what) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(kLdsFloats * sizeof(float)));
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
-    return MCMC_OK;
+    return ensure_dyn_lds(reinterpret_cast<const void*>(kernel), kLdsFloats * sizeof(float), what);
 }
 
 }  // namespace

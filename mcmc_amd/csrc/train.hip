@@ -335,9 +335,7 @@ static Tiles pick_tiles(int64_t pairs, int row_blocks) {
 
 template <typename K>
 static int set_dyn_lds(K kern, size_t lds, const char* what) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return set_error(MCMC_EHIP, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
-    return MCMC_OK;
+    return ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, what);
 }
 
 #define MCMC_TRAIN_PICK(NS, KERNEL, mode) ((mode) == 1 ? NS::KERNEL<1> : (mode) == 2 ? NS::KERNEL<2> : NS::KERNEL<0>)

@@ -313,11 +313,13 @@ class Engine:
     def forward(self, dtype: int, xpack, B: int, F: int, wpack, pair_count: int, Y: torch.Tensor, ldY: int,
                 masks=None, keep_scale: float = 1.0, philox_dropout: Optional[Tuple[int, float, int, int, int]] = None):
         """masks: three host keep-masks [pair_count, B, 256/128/64] uint8 (train-mode forward);
-        philox_dropout: (mask_seed, p_drop, n_members, n_samples, pair_begin) for counter-based masks."""
+        philox_dropout: (mask_seed, p_drop, n_members, n_samples, pair_begin[, row_begin]) for counter-based masks;
+        row_begin = global index of this launch's first row (the masks are keyed by the global row)."""
         if philox_dropout is not None:
-            mseed, p_drop, M, S, pair_begin = philox_dropout
+            mseed, p_drop, M, S, pair_begin = philox_dropout[:5]
+            row_begin = philox_dropout[5] if len(philox_dropout) > 5 else 0
             _lib.check(self.lib.mcmc_forward_dropout(self.ctx.handle, dtype, _p(xpack), B, F, _p(wpack), M, S, pair_begin, pair_count,
-                                                     mseed & 0xFFFFFFFFFFFFFFFF, float(p_drop), _p(Y), ldY, _stream()),
+                                                     mseed & 0xFFFFFFFFFFFFFFFF, float(p_drop), row_begin, _p(Y), ldY, _stream()),
                        "mcmc_forward_dropout")
             return
         m0 = m1 = m2 = None
@@ -457,6 +459,62 @@ def plan_chunks(n_pairs_max: int, B: int, chunk_bytes: int, chunk_pairs: Optiona
     return cn, (per + ROW_GRANULE - 1) // ROW_GRANULE * ROW_GRANULE
 
 
+@dataclass(frozen=True)
+class RankPlan:
+    """What one rank of a (possibly sharded) predict does."""
+    q_begin: int          # its contiguous range of processing indices q: [q_begin, q_end)
+    q_end: int
+    pairs_per_chunk: int  # pairs per forward / reduce launch (Cn): the whole shard unless pairs are chunked
+    hoisted: bool         # one pair chunk: the shard's weights are sampled once and serve every row block
+    pilot_share: int      # pilot pairs this rank reduces per row block: those of q < n_pilot inside its FIRST chunk
+
+    @property
+    def n_local(self) -> int:
+        return self.q_end - self.q_begin
+
+    def chunks(self) -> List[Tuple[int, int]]:
+        """(first q, count) of every pair chunk, in launch order."""
+        return [(b, min(self.pairs_per_chunk, self.q_end - b)) for b in range(self.q_begin, self.q_end, self.pairs_per_chunk)]
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """The shard / chunk / pilot plan of one predict: a pure function of sizes, world and constants, identical on every
+    rank (no rank learns anything from another one to build it)."""
+    n_pairs: int                          # N = M * S
+    world: int
+    chunk_pairs: int                      # Cplan: pairs per chunk as planned for the LARGEST shard
+    rows_per_block: int                   # Rb: every rank walks the same row blocks
+    row_blocks: Tuple[Tuple[int, int], ...]  # (first row, rows)
+    n_pilot: int                          # the pilot pairs are the global q < n_pilot, whoever owns them
+    n_pilot_total: int                    # sum of the ranks' pilot shares (== n_pilot: checked by the CPU tests)
+    ranks: Tuple[RankPlan, ...]
+
+
+def plan_predict(N: int, M: int, B: int, world: int = 1, shard_weights: Optional[Sequence[float]] = None, *,
+                 chunk_bytes: int = CHUNK_BYTES, chunk_pairs: Optional[int] = None, chunk_rows: Optional[int] = None) -> ShardPlan:
+    """Shards (contiguous q-ranges, equal or weighted), pair chunks, row blocks and the pilot's split over the ranks.
+
+    Invariants (tests/test_host_logic.py, world 1..8, equal / weighted / empty shards, chunked and un-chunked pairs):
+    the q-ranges tile [0, N) in rank order; every rank gets the same row blocks; the pilot pairs q < n_pilot lie in
+    their owner's first pair chunk, so each row block's pilot is complete after the first forward launch of every
+    rank; the shares add up to n_pilot, which every rank knows without an exchange."""
+    sw = shard_weights if world > 1 else None
+    bounds = [shard_pairs(N, r, world, sw) for r in range(world)]
+    n_max = max(e - b for b, e in bounds)  # the largest shard: the chunk plan must not differ between ranks
+    Cplan, Rb = plan_chunks(n_max, B, chunk_bytes, chunk_pairs, chunk_rows, M)
+    # bounded by the pair chunk only when pairs ARE chunked, so that the pilot pairs sit in every owner's first chunk
+    # and the choice does not depend on the world size
+    n_pilot = min(pilot_pairs(N, M), Cplan if Cplan < n_max else N)
+    ranks = []
+    for b, e in bounds:
+        n_local = e - b
+        cn = max(1, min(Cplan, max(n_local, 1)))
+        ranks.append(RankPlan(b, e, cn, cn >= n_local, max(0, min(min(Cplan, n_local), n_pilot - b))))
+    blocks = tuple((r0, min(Rb, B - r0)) for r0 in range(0, B, max(Rb, 1)))
+    return ShardPlan(N, world, Cplan, Rb, blocks, n_pilot, sum(r.pilot_share for r in ranks), tuple(ranks))
+
+
 def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples: int, *, dtype="fp32",
                noise: str = "philox", eps: Optional[torch.Tensor] = None, seed: int = 0,
                q_levels: Sequence[float] = (), nbins: int = 128, range_sigmas: float = 6.0,
@@ -479,7 +537,8 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     (start, end) torch.cuda.Event pairs recorded on the launch stream around each launch.
     ``mc_dropout`` (extension; the reference's predict() runs in eval mode, bayesian_ensemble.py:215-216):
     keep the members' Dropout(p_drop) live, with counter-based Philox masks keyed by (mask_seed or seed;
-    global pair id, row, element) applied inside the MFMA kernels' activation stage.
+    global pair id, GLOBAL row, element) applied inside the MFMA kernels' activation stage: like the weight noise, the
+    masks do not depend on how the pairs and rows are cut into launches, nor on the world size.
     """
     import torch.distributed as dist
     dev_index = _require_gpu(X, "X")
@@ -513,28 +572,15 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
     sharded = group is not False and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if sharded else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    q_begin, q_end = shard_pairs(N, rank, world, shard_weights if world > 1 else None)
-    n_local = q_end - q_begin
+    plan = plan_predict(N, M, B, world, shard_weights, chunk_bytes=chunk_bytes, chunk_pairs=chunk_pairs, chunk_rows=chunk_rows)
+    me = plan.ranks[rank]
+    q_begin, q_end, n_local, Cn, Rb = me.q_begin, me.q_end, me.n_local, me.pairs_per_chunk, plan.rows_per_block
+    n_pilot, n_pilot_total = plan.n_pilot, plan.n_pilot_total
 
     with torch.cuda.device(eng.device):
         xpack = eng.pack_x(X, dt)
         wbytes = eng.wpack_bytes(F, dt)
         xrow_bytes = eng.lib.mcmc_xpack_bytes(32, F, dt) // 32
-        # the largest shard: the chunk plan must not differ between ranks
-        n_max = max(e - b for b, e in (shard_pairs(N, r, world, shard_weights if world > 1 else None) for r in range(world)))
-        # Philox dropout masks are keyed by the row index inside a launch: that mode keeps whole rows per launch
-        Cplan, Rb = plan_chunks(n_max, B, chunk_bytes, chunk_pairs or (max(1, chunk_bytes // (((B + 63) // 64 * 64) * 4)) if mc_dropout else None),
-                                chunk_rows, M)
-        Cn = max(1, min(Cplan, max(n_local, 1)))
-        # pilot pairs q < n_pilot, whichever ranks own them; bounded by the pair chunk only when pairs ARE chunked, so that
-        # they sit in every owner's first chunk and the choice does not depend on the world size
-        n_pilot = min(pilot_pairs(N, M), Cplan if Cplan < n_max else N)
-        # what the ranks' pilot contributions add up to (each owner gives the pilot pairs of its FIRST chunk): known on
-        # every rank without asking, so the pilot combine needs no count exchange and no host sync
-        n_pilot_total = 0
-        for r in range(world):
-            b_r, e_r = shard_pairs(N, r, world, shard_weights if world > 1 else None)
-            n_pilot_total += max(0, min(min(Cplan, e_r - b_r), n_pilot - b_r))
         ldY = (min(Rb, B) + 63) // 64 * 64
         Y = torch.empty(Cn, ldY, dtype=torch.float32, device=eng.device)
         wpack = torch.empty(Cn * wbytes, dtype=torch.uint8, device=eng.device)
@@ -543,7 +589,7 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
         samples = torch.empty(N, B, dtype=torch.float32, device=eng.device) if return_samples else None
         if return_samples and world > 1:
             raise ValueError("return_samples is a single-process debugging aid")
-        hoisted = Cn >= n_local  # one pair chunk: its weights are sampled once and serve every row block
+        hoisted = me.hoisted  # one pair chunk: its weights are sampled once and serve every row block
         if hoisted and n_local:
             with _timed(timers, "sample_weights"):
                 eng.sample_weights(mu, rho, S, F, q_begin, n_local, mode, eps, seed, dt, wpack)
@@ -551,8 +597,7 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
         def rows_of(t: torch.Tensor, r0: int, rb: int):
             return t[r0:r0 + rb]
 
-        for r0 in range(0, B, max(Rb, 1)):
-            rb = min(Rb, B - r0)
+        for r0, rb in plan.row_blocks:
             xblk = xpack[r0 * xrow_bytes:]  # row blocks start on whole superblocks: 16-byte aligned
             blk = ReduceState(0, rows_of(st.sum, r0, rb), rows_of(st.sumsq, r0, rb), nbins=st.nbins)
             if nq:
@@ -565,14 +610,14 @@ def mc_predict(X: torch.Tensor, mu: torch.Tensor, rho: torch.Tensor, num_samples
                         eng.sample_weights(mu, rho, S, F, begin, cnt, mode, eps, seed, dt, wpack)
                 with _timed(timers, "forward", cnt * rb):
                     eng.forward(dt, xblk, rb, F, wpack, cnt, Y, ldY,
-                                philox_dropout=(seed if mask_seed is None else mask_seed, p_drop, M, S, begin) if mc_dropout else None)
+                                philox_dropout=(seed if mask_seed is None else mask_seed, p_drop, M, S, begin, r0) if mc_dropout else None)
                 if nq and first:
                     # pilot: the moments of global pairs q < n_pilot place every row's histogram.  They sit at the head of
                     # the ranks that own them (rank 0 alone when its shard has >= n_pilot pairs) and in their first chunk;
                     # every rank joins the sum, so all ranks bin identically.
                     with _timed(timers, "pilot"):
                         pblk = ReduceState(0, rows_of(pilot.sum, r0, rb), rows_of(pilot.sumsq, r0, rb))
-                        mine = max(0, min(cnt, n_pilot - begin))
+                        mine = me.pilot_share  # = max(0, min(cnt, n_pilot - begin)) in the rank's first chunk
                         if mine:
                             eng.reduce_update(Y, ldY, mine, rb, pblk)
                         pblk = combine_partials(pblk, group, n_total=n_pilot_total)

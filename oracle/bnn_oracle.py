@@ -278,15 +278,16 @@ def philox_eps(seed: int, pair_ids: Sequence[int], P: int) -> np.ndarray:
 
 
 
-def philox_keep_masks(seed: int, pair: int, rows: int, p_drop: float = P_DROP):
-    """Dropout keep-masks [rows,256],[rows,128],[rows,64] of one pair from the 'MASK' Philox stream.
+def philox_keep_masks(seed: int, pair: int, rows: int, p_drop: float = P_DROP, row_begin: int = 0):
+    """Dropout keep-masks [rows,256],[rows,128],[rows,64] of one pair from the 'MASK' Philox stream, for the global rows
+    row_begin .. row_begin + rows - 1.
 
     Counter = (elem>>2, pair, 0x4D41534B ['MASK'], row), key = seed; component elem&3;
     elem runs over the 448 hidden activations (256 | 128 | 64); keep iff u01 < 1-p (fp32 compare).
     Same keying as mcmc_amd/csrc/philox.hpp:philox_mask_uniform / train.hip:keep_flag.
     """
     n_el = sum(HIDDEN)
-    row = np.arange(rows, dtype=np.uint32)[:, None]
+    row = (np.arange(rows, dtype=np.int64) + row_begin).astype(np.uint32)[:, None]
     elem = np.arange(n_el, dtype=np.uint32)[None, :]
     row, elem = np.broadcast_arrays(row, elem)
     ctr = np.stack([elem >> np.uint32(2), np.full_like(elem, pair), np.full_like(elem, 0x4D41534B), row], axis=-1)

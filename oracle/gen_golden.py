@@ -14,6 +14,12 @@ What is captured:
                       ``eps_seed`` with torch's CPU generator in the reference's draw order
                       (oracle.reference_rng_eps); stores mean, std, quantiles and a slice
                       of all_predictions.
+  predict_trained.npz the reference's own train() (main.py:169: 5 members, batch 32, 10 samples per step, 40 epochs,
+                      seeded, CPU) on the config-1 series, then its predict() (main.py:170) with recorded noise:
+                      the TRAINED (mu, rho), X, y, mean, std, quantiles, head / tail of all_predictions; eps is
+                      regenerated from ``eps_seed`` like predict_cfg1.  Pins the predict kernels on the weight and
+                      pre-activation distribution a trained ensemble has (every other predict fixture uses
+                      init-time members).
   train_fwd.npz       train-mode forward (noise + live dropout masks, captured by a forward
                       hook on model.dropout): eps, masks, outputs.
   loss.npz            peak_weighted_loss value + autograd grad at N in {1, 13, 32, 4096}.
@@ -188,6 +194,45 @@ def gen_predict_cfg1():
                         q_levels=np.array(Q_LEVELS), quantiles=q.numpy(),
                         all_predictions_head=allp[:8].numpy(), all_predictions_tail=allp[-4:].numpy(),
                         descaled_mean=descaled_mean, descaled_std=descaled_std)
+
+
+def gen_predict_trained(epochs: int = 40):
+    """main.py:169-170 on the reference itself: train() then predict() on the config-1 series."""
+    import contextlib
+    import io
+    M, S = 5, 100
+    X_raw, y_raw, Xs, ys, y_scale, y_mean = make_cfg1_inputs(seed=2025)
+    ens = GPUBayesianEnsemble(input_dim=Xs.shape[1], n_models=M, device=torch.device("cpu"), batch_size=32)
+    torch.manual_seed(777)
+    log = io.StringIO()
+    with contextlib.redirect_stdout(log):
+        ens.train(Xs.refine_names("time", "features"), ys.refine_names("time"), epochs=epochs, num_samples=10)
+    assert len(ens.models) == M
+    members = list(ens.models)
+    eps_seed = 54321
+    mean, std, eps = run_reference_predict(members, Xs, S, eps_seed=eps_seed)
+    assert torch.equal(eps, orc.reference_rng_eps(eps_seed, M, S, 11))
+    allp = reference_all_predictions(members, Xs, eps)
+    assert torch.equal(allp.mean(0), mean) and torch.equal(allp.std(0), std)
+    mu, rho = orc.pack_members(members)
+    q = torch.quantile(allp, torch.tensor(Q_LEVELS), dim=0)
+    # the largest pre-activations of the trained members at sample=False: what the bf16 kernels' ELU range has to cover
+    with torch.no_grad():
+        zmax = []
+        for net in members:
+            h = Xs
+            for layer in net.hidden_layers:
+                z = layer(h, sample=False)
+                zmax.append(float(z.abs().max()))
+                h = torch.nn.functional.elu(z)
+    np.savez_compressed(os.path.join(OUT, "predict_trained.npz"), X=Xs.numpy(), y=ys.numpy(), y_scale=y_scale, y_mean=y_mean,
+                        mu=mu.numpy(), rho=rho.numpy(), eps_seed=eps_seed, M=M, S=S, epochs=epochs, mean=mean.numpy(), std=std.numpy(),
+                        q_levels=np.array(Q_LEVELS), quantiles=q.numpy(), all_predictions_head=allp[:8].numpy(),
+                        all_predictions_tail=allp[-4:].numpy(), preact_absmax=np.array(zmax).reshape(M, 3),
+                        train_log=np.array(log.getvalue().splitlines()[-6:]))
+    resid = (mean - ys).pow(2).mean().sqrt()
+    print(f"predict_trained: {epochs} epochs; scaled-space RMSE of the mean {float(resid):.3f}; mean std {float(std.mean()):.3f}; "
+          f"|mu| max {float(mu.abs().max()):.2f}, rho range [{float(rho.min()):.2f}, {float(rho.max()):.2f}]; pre-activation max {max(zmax):.1f}")
 
 
 def gen_train_fwd():
@@ -430,12 +475,9 @@ def gen_glue():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_predict_small()
-    gen_predict_cfg1()
-    gen_train_fwd()
-    gen_loss()
-    gen_train_steps()
-    gen_glue()
-    gen_tft()
+    gens = dict(predict_small=gen_predict_small, predict_cfg1=gen_predict_cfg1, predict_trained=gen_predict_trained,
+                train_fwd=gen_train_fwd, loss=gen_loss, train_steps=gen_train_steps, glue=gen_glue, tft=gen_tft)
+    for name in (sys.argv[1:] or list(gens)):  # no argument: every fixture
+        gens[name]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

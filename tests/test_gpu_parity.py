@@ -87,8 +87,50 @@ def test_bf16_config2_within_2e2(golden, dtype):
     got = res.samples.cpu().numpy()
     scale = float(allp.abs().max())
     assert np.max(np.abs(got - allp.numpy())) <= 2e-2 * scale
-    # bf16 samples are themselves perturbed: allow the bf16 error on top of one bin
-    assert np.all(np.abs(res.quantiles.cpu().numpy() - g["quantiles"]) <= width[None, :] + 2e-2 * scale)
+    # the histogram itself: within ONE bin of torch.quantile over the kernel's own (bf16-perturbed) samples ...
+    q = res.quantiles.cpu().numpy()
+    own = torch.quantile(res.samples.cpu(), torch.tensor(Q), dim=0).numpy()
+    assert _bins_off(q, own, width) <= 1.0
+    # ... and against the reference's fp32 quantiles: one bin + what the bf16 samples themselves moved the bounds by
+    shift = np.max(np.abs(own - g["quantiles"]), axis=0)
+    assert np.all(np.abs(q - g["quantiles"]) <= width[None, :] + shift[None, :])
+    assert float(shift.max()) <= 2e-2 * scale
+
+
+def _bins_off(q, q_ref, width):
+    """Largest distance of interval bounds from their reference, in histogram bins of the row."""
+    return float(np.max(np.abs(q.astype(np.float64) - q_ref.astype(np.float64)) / width[None, :].astype(np.float64)))
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2), ("bf16_fast", 2e-2)])
+def test_trained_members_predict(golden, dtype, tol):
+    """The reference's use is train() then predict() (main.py:169-170): members trained by the REFERENCE (40 epochs on the
+    config-1 series; pre-activations up to 27, rho -3.6 .. -2.3) through every kernel on the reference's own noise stream.
+    fp32: 1e-5; both bf16 kernels: per-sample outputs, mean and std within the north star's 2e-2.  Interval bounds: within
+    one bin of torch.quantile over the kernel's OWN samples (isolates the histogram from the bf16 perturbation), and within
+    one bin + the measured shift of the samples against the reference's fp32 quantiles."""
+    g = golden("predict_trained.npz")
+    M, S = int(g["M"]), int(g["S"])
+    eps = orc.reference_rng_eps(int(g["eps_seed"]), M, S, 11)
+    res = _run(g, dtype, S, eps, nbins=128)
+    got = res.samples.cpu().numpy()
+    scale = max(1.0, float(np.abs(g["all_predictions_head"]).max()))
+    assert np.max(np.abs(got[:8] - g["all_predictions_head"])) <= max(tol, 2e-5) * scale
+    assert np.max(np.abs(got[-4:] - g["all_predictions_tail"])) <= max(tol, 2e-5) * scale
+    _check_stats(res, g["mean"], g["std"], tol)
+    width = res.bin_width.cpu().numpy()
+    q = res.quantiles.cpu().numpy()
+    own = torch.quantile(res.samples.cpu(), torch.tensor(Q), dim=0).numpy()
+    assert _bins_off(q, own, width) <= 1.0, (dtype, _bins_off(q, own, width))
+    if dtype == "fp32":
+        assert _bins_off(q, g["quantiles"], width) <= 1.0
+    else:
+        allp = orc.predict_all(torch.from_numpy(g["X"]), torch.from_numpy(g["mu"]), torch.from_numpy(g["rho"]), eps).numpy()
+        assert np.max(np.abs(got - allp)) <= tol * max(1.0, float(np.abs(allp).max()))
+        shift = np.max(np.abs(own - g["quantiles"]), axis=0)  # what the bf16 samples themselves moved the bounds by, per row
+        assert np.all(np.abs(q - g["quantiles"]) <= width[None, :] + shift[None, :])
+        print(f"[{dtype}] trained members: bounds {_bins_off(q, own, width):.2f} bins from torch.quantile of the kernel's samples, "
+              f"{_bins_off(q, g['quantiles'], width):.2f} bins from the reference's fp32 quantiles")
 
 
 def test_train_mode_masks_fp32(golden):
@@ -313,13 +355,15 @@ def test_ensemble_class_contract(golden):
 
 @pytest.mark.parametrize("dtype", ["bf16", "bf16_fast"])
 def test_config3_full_size_properties(dtype):
-    """BASELINE configs[2] at full row count (10k series x 365 = 3.65 M rows, 8 members, bf16,
-    Philox) with a reduced sample count: size-independent properties + a row subsample against
-    the fp32 CPU restatement fed with the CPU restatement of the same Philox counters (2e-2)."""
+    """BASELINE configs[2] at full row count (10k series x 365 = 3.65 M rows, 8 members, bf16, Philox) with 128 samples per
+    member (1,024 samples per row): size-independent properties + a 1,024-row subsample against the fp32 CPU restatement
+    fed with the CPU restatement of the same Philox counters: mean / std within 2e-2 for BOTH bf16 kernels; interval bounds
+    within one bin of torch.quantile over the same-dtype samples (re-computed by the kernel on the subsample's rows: row
+    results do not depend on the launch shape), and within one bin + the measured bf16 shift of the fp32 quantiles."""
     from mcmc_amd import BayesianNetwork, mc_predict, pack_members
     from mcmc_amd.data import make_series_batch
     d = _dev()
-    M, S, seed = 8, 12, 424242
+    M, S, seed = 8, 128, 424242
     X, _ = make_series_batch(10_000, seed=2025, device=d)
     assert X.shape == (3_650_000, 11)
     torch.manual_seed(1)
@@ -335,27 +379,53 @@ def test_config3_full_size_properties(dtype):
     assert torch.isfinite(res.mean).all() and torch.isfinite(res.std).all() and (res.std > 0).all()
     # quantiles are sorted and bracket the mean's neighbourhood
     assert (res.quantiles[0] <= res.quantiles[1]).all() and (res.quantiles[1] <= res.quantiles[2]).all()
-    # chunking (and hence launch shape) must not change the moments: fp64 sums of identical samples
-    res2 = mc_predict(X, mu, rho, S, dtype=dtype, noise="philox", seed=seed, q_levels=q, nbins=128, chunk_pairs=40)
-    assert torch.allclose(res2.mean, res.mean, rtol=0, atol=1e-6)
-    assert torch.allclose(res2.std, res.std, rtol=1e-6, atol=1e-7)
     # identical rows (same calendar day, same indicators) give identical statistics
     Xc = X.cpu()
     same = (Xc[:365 * 50:365] == Xc[0]).all(dim=1).nonzero().flatten()
     if len(same) > 1:
         i, j = int(same[0]) * 365, int(same[1]) * 365
         assert float(res.mean[i]) == float(res.mean[j]) and float(res.std[i]) == float(res.std[j])
-    # row subsample vs the oracle on the same noise
-    idx = torch.randperm(X.shape[0], generator=torch.Generator().manual_seed(0))[:48]
+    # row subsample (1,024 rows x 1,024 samples) vs the oracle on the same noise
+    idx = torch.randperm(X.shape[0], generator=torch.Generator().manual_seed(0))[:1024]
     eps = torch.from_numpy(orc.philox_eps(seed, range(M * S), mu.shape[1])).reshape(M, S, -1)
     allp = orc.predict_all(Xc[idx], mu.cpu(), rho.cpu(), eps)
     m_ref, s_ref = orc.reduce_mean_std(allp)
     scale = torch.maximum(m_ref.abs(), s_ref)
-    assert float(((res.mean.cpu()[idx] - m_ref).abs() / scale).max()) <= 2e-2
-    assert float(((res.std.cpu()[idx] - s_ref).abs() / s_ref).max()) <= 2e-2
-    tq = torch.quantile(allp, torch.tensor(q), dim=0)
-    width = res.bin_width.cpu()[idx]
-    assert ((res.quantiles.cpu()[:, idx] - tq).abs() <= width[None, :] + 2e-2 * scale[None, :]).all()
+    e_mean = float(((res.mean.cpu()[idx] - m_ref).abs() / scale).max())
+    e_std = float(((res.std.cpu()[idx] - s_ref).abs() / s_ref).max())
+    assert e_mean <= 2e-2 and e_std <= 2e-2, (dtype, e_mean, e_std)
+    # the same rows alone, samples returned: identical statistics (rows are independent of the launch shape), and the
+    # kernel's own samples for the same-dtype quantile check
+    sub = mc_predict(X[idx.to(d)].contiguous(), mu, rho, S, dtype=dtype, noise="philox", seed=seed, q_levels=q, nbins=128, return_samples=True)
+    assert torch.allclose(sub.mean, res.mean[idx.to(d)], rtol=0, atol=1e-6) and torch.allclose(sub.quantiles, res.quantiles[:, idx.to(d)], rtol=0, atol=1e-5)
+    samples = sub.samples.cpu()
+    assert float((samples - allp).abs().max()) <= 2e-2 * max(1.0, float(allp.abs().max()))
+    width = res.bin_width.cpu()[idx].numpy()
+    got_q = res.quantiles.cpu()[:, idx].numpy()
+    own = torch.quantile(samples, torch.tensor(q), dim=0).numpy()
+    tq = torch.quantile(allp, torch.tensor(q), dim=0).numpy()
+    bins_own, bins_ref = _bins_off(got_q, own, width), _bins_off(got_q, tq, width)
+    print(f"[{dtype}] config 3, 1,024 rows x 1,024 samples: mean {e_mean:.2e}, std {e_std:.2e}; bounds {bins_own:.2f} bins from "
+          f"torch.quantile of the same-dtype samples, {bins_ref:.2f} bins from the fp32 oracle's")
+    assert bins_own <= 1.0
+    shift = np.max(np.abs(own - tq), axis=0)
+    assert np.all(np.abs(got_q - tq) <= width[None, :] + shift[None, :])
+
+
+def test_config3_chunking_does_not_change_moments():
+    """Full row count, few samples: pair chunks (state read-modify-write per chunk) against the default row blocks."""
+    from mcmc_amd import BayesianNetwork, mc_predict, pack_members
+    from mcmc_amd.data import make_series_batch
+    d = _dev()
+    M, S, seed = 8, 12, 424242
+    X, _ = make_series_batch(10_000, seed=2025, device=d)
+    torch.manual_seed(1)
+    mu, rho = pack_members([BayesianNetwork(11) for _ in range(M)], d)
+    q = (0.025, 0.5, 0.975)
+    res = mc_predict(X, mu, rho, S, dtype="bf16_fast", noise="philox", seed=seed, q_levels=q, nbins=128)
+    res2 = mc_predict(X, mu, rho, S, dtype="bf16_fast", noise="philox", seed=seed, q_levels=q, nbins=128, chunk_pairs=40)
+    assert torch.allclose(res2.mean, res.mean, rtol=0, atol=1e-6)
+    assert torch.allclose(res2.std, res.std, rtol=1e-6, atol=1e-7)
 
 
 def test_histogram_counts_sum_and_determinism(golden):
@@ -411,7 +481,7 @@ def test_c_abi_rejects_bad_arguments():
                                                 (__import__("ctypes").c_double * 1)(0.5), 1, _p(Y), _p(Y), _p(Y), _stream()), "x")
     # the fast bf16 image has no dropout-mask stage
     with pytest.raises(ValueError, match="MCMC_DT_BF16_FAST"):
-        _lib.check(eng.lib.mcmc_forward_dropout(eng.ctx.handle, 2, _p(Y), 64, 11, _p(Y), 2, 3, 0, 1, 0, 0.1, _p(Y), 64, _stream()), "x")
+        _lib.check(eng.lib.mcmc_forward_dropout(eng.ctx.handle, 2, _p(Y), 64, 11, _p(Y), 2, 3, 0, 1, 0, 0.1, 0, _p(Y), 64, _stream()), "x")
     # empty inputs are accepted and do nothing
     assert eng.lib.mcmc_forward(eng.ctx.handle, 0, None, 0, 11, None, 0, None, None, None, 1.0, None, 0, _stream()) == 0
 
@@ -420,13 +490,12 @@ def test_c_abi_rejects_bad_arguments():
 @pytest.mark.parametrize("dtype,tol", [("fp32", 1e-5), ("bf16", 2e-2), ("bf16_fast", 2e-2)])
 def test_input_widths_across_the_k_granule(F, B, dtype, tol):
     """Every input width class: F+1 (bias column) below / at / above the 16-wide bf16 K granule and the
-    kernel's maximum (24), against the oracle's per-pair outputs on the same injected noise.
-    The statistics here are over SIX samples, so their relative error is that of single outputs: the exact
-    bf16 path stays within 5e-2, the exponent-field ELU (whose error is about twice as large: 0.03 - 0.07
-    measured, restated on the CPU by tools/elu_approx_study.py) is held to 1e-1."""
+    kernel's maximum (24), against the oracle on the same injected noise: every per-pair output within the north star's
+    tolerance (2e-2 of max|y| for both bf16 kernels), and the mean / std over 2 x 64 = 128 samples within the same 2e-2
+    (the statistic of a handful of samples has the relative error of single outputs, so it is taken over 128)."""
     from mcmc_amd import mc_predict
     g = torch.Generator().manual_seed(1000 + F)
-    M, S = 2, 3
+    M, S = 2, 64
     P = orc.n_params(F)
     X = torch.randn(B, F, generator=g)
     mu = torch.zeros(M, P)
@@ -443,7 +512,7 @@ def test_input_widths_across_the_k_granule(F, B, dtype, tol):
     scale = max(1.0, float(np.abs(ref).max()))
     assert np.max(np.abs(got - ref)) <= tol * scale, (F, B, dtype, float(np.max(np.abs(got - ref))), scale)
     m_ref, s_ref = orc.reduce_mean_std(torch.from_numpy(ref))
-    _check_stats(res, m_ref.numpy(), s_ref.numpy(), {"fp32": tol, "bf16": 5e-2, "bf16_fast": 1e-1}[dtype])
+    _check_stats(res, m_ref.numpy(), s_ref.numpy(), tol)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16_fast"])
@@ -499,6 +568,35 @@ def test_mc_dropout_philox_masks_match_oracle(golden, dtype, tol):
     assert float((plain.samples - res.samples).abs().max()) > 1e-3  # the masks did something
     chunked = mc_predict(X.to(d), mu.to(d), rho.to(d), S, chunk_pairs=5, **kw)
     assert torch.equal(chunked.samples, res.samples)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_mc_dropout_independent_of_row_blocks(dtype):
+    """Philox dropout masks are keyed by the GLOBAL row (mcmc_forward_dropout's row_begin): an MC-dropout predict cut into
+    row blocks - and into row blocks x pair chunks - gives bit for bit the samples of one launch over all rows."""
+    from mcmc_amd import mc_predict
+    d = _dev()
+    g = torch.Generator().manual_seed(11)
+    B, F, M, S = 40_001, 11, 2, 3
+    P = orc.n_params(F)
+    X = torch.randn(B, F, generator=g).to(d)
+    mu = (torch.randn(M, P, generator=g) * 0.08).to(d)
+    rho = (-3.0 + 0.3 * torch.randn(M, P, generator=g)).to(d)
+    kw = dict(dtype=dtype, seed=5, return_samples=True, mc_dropout=True, mask_seed=99)
+    whole = mc_predict(X, mu, rho, S, **kw)
+    blocks = mc_predict(X, mu, rho, S, chunk_rows=16384, **kw)
+    both = mc_predict(X, mu, rho, S, chunk_rows=16384, chunk_pairs=4, **kw)
+    assert torch.equal(blocks.samples, whole.samples) and torch.equal(both.samples, whole.samples)
+    plain = mc_predict(X, mu, rho, S, dtype=dtype, seed=5, return_samples=True)
+    assert float((plain.samples - whole.samples).abs().max()) > 1e-3  # the masks did something
+    # a row deep inside the third block against the oracle fed the oracle's restatement of the same mask stream
+    row = 16384 * 2 + 4321
+    eps = torch.from_numpy(orc.philox_eps(5, range(M * S), P)).reshape(M, S, P)
+    for p in (0, M * S - 1):
+        masks = [torch.from_numpy(m) for m in orc.philox_keep_masks(99, p, 1, row_begin=row)]
+        ref = orc.forward_pair(X[row:row + 1].cpu(), mu.cpu()[p // S], rho.cpu()[p // S], eps[p // S, p % S], masks=masks)
+        tol = 1e-4 if dtype == "fp32" else 2e-2
+        assert abs(float(whole.samples[p, row]) - float(ref[0])) <= tol * max(1.0, abs(float(ref[0])))
 
 
 def test_bf16_host_masks_equal_philox_masks(golden):

@@ -183,6 +183,82 @@ def test_shard_pairs_weighted():
         shard_pairs(10, 0, 2, [1.0])
 
 
+_PLAN_CASES = [
+    # (N, M, B, chunk_bytes, chunk_pairs, chunk_rows)
+    (8192, 8, 3_650_000, 8 << 30, None, None),     # config 3 / 4: row blocks of all pairs
+    (8192, 8, 3_650_000, 8 << 30, 40, None),       # explicit pair chunks, whole rows
+    (8192, 8, 3_650_000, 1 << 26, None, None),     # a tight sample buffer: pairs AND rows chunked
+    (500, 5, 365, 8 << 30, None, None),            # config 1 / 2
+    (500, 5, 365, 8 << 30, 35, None),
+    (40, 8, 40_001, 8 << 30, 12, 16384),           # row blocks x pair chunks, ragged last block
+    (6, 3, 10, 8 << 30, None, None),               # fewer pairs than ranks at world 8: empty shards
+    (200_000, 8, 50_000, 8 << 30, None, None),     # > 131,072 pairs: chunked by the plan itself
+]
+_PLAN_WEIGHTS = {1: [None], 2: [None, [1.0, 0.6]], 3: [None, [1.0, 1.0, 0.5]], 4: [None, [1.0, 0.9, 1.1, 1.0]],
+                 8: [None, [1.0, 0.9, 1.1, 1.0, 1.0, 0.95, 1.05, 1.0], [100.0, 1, 1, 1, 1, 1, 1, 1e-3]]}
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("case", _PLAN_CASES)
+def test_predict_plan_invariants(world, case):
+    """The shard / chunk / pilot plan mc_predict consumes (engine.plan_predict), world 1..8, equal and weighted shards
+    (including shards of zero pairs), chunked and un-chunked pairs: the q-ranges tile [0, N) exactly; every rank walks the
+    same row blocks, which tile [0, B); the pilot pairs q < n_pilot lie in their owner's FIRST pair chunk; the ranks'
+    pilot shares add up to n_pilot_total == n_pilot; and the plan is the same whichever rank computes it (a pure function)."""
+    from mcmc_amd.engine import ROW_GRANULE, pilot_pairs, plan_predict
+    N, M, B, chunk_bytes, chunk_pairs, chunk_rows = case
+    for weights in _PLAN_WEIGHTS[world]:
+        plan = plan_predict(N, M, B, world, weights, chunk_bytes=chunk_bytes, chunk_pairs=chunk_pairs, chunk_rows=chunk_rows)
+        assert plan == plan_predict(N, M, B, world, weights, chunk_bytes=chunk_bytes, chunk_pairs=chunk_pairs, chunk_rows=chunk_rows)
+        assert len(plan.ranks) == world
+        # q-ranges: exact, contiguous, in rank order
+        assert plan.ranks[0].q_begin == 0 and plan.ranks[-1].q_end == N
+        assert all(plan.ranks[r].q_end == plan.ranks[r + 1].q_begin for r in range(world - 1))
+        assert all(rk.q_begin <= rk.q_end for rk in plan.ranks)
+        # row blocks: identical for every rank by construction (one tuple), tile [0, B), whole superblocks except the last
+        assert plan.row_blocks[0][0] == 0 and sum(rb for _, rb in plan.row_blocks) == B
+        assert all(plan.row_blocks[i][0] + plan.row_blocks[i][1] == plan.row_blocks[i + 1][0] for i in range(len(plan.row_blocks) - 1))
+        assert all(rb % ROW_GRANULE == 0 for _, rb in plan.row_blocks[:-1]) and all(rb > 0 for _, rb in plan.row_blocks)
+        # the sample buffer of the largest shard respects the bound (one superblock of one pair is the floor)
+        n_max = max(rk.n_local for rk in plan.ranks)
+        ld = (min(plan.rows_per_block, B) + 63) // 64 * 64
+        if chunk_pairs is None and chunk_rows is None:
+            assert min(plan.chunk_pairs, n_max) * ld * 4 <= max(chunk_bytes, min(ld, ROW_GRANULE) * 4)
+        # pilot
+        assert 0 < plan.n_pilot <= min(N, max(M, pilot_pairs(N, M)))
+        assert plan.n_pilot_total == plan.n_pilot == sum(rk.pilot_share for rk in plan.ranks)
+        for rk in plan.ranks:
+            chunks = rk.chunks()
+            assert sum(c for _, c in chunks) == rk.n_local and all(0 < c <= rk.pairs_per_chunk for _, c in chunks)
+            assert rk.hoisted == (len(chunks) <= 1)
+            mine = [q for q in range(rk.q_begin, rk.q_end) if q < plan.n_pilot]
+            assert len(mine) == rk.pilot_share
+            if mine:  # every pilot pair of this rank sits in its first chunk
+                b0, c0 = chunks[0]
+                assert b0 <= mine[0] and mine[-1] < b0 + c0
+        # the pilot set is world-independent unless the pair chunk bounds it (then it is bounded by constants and n_max only)
+        one = plan_predict(N, M, B, 1, None, chunk_bytes=chunk_bytes, chunk_pairs=chunk_pairs, chunk_rows=chunk_rows)
+        if plan.chunk_pairs >= n_max and one.chunk_pairs >= N:
+            assert plan.n_pilot == one.n_pilot
+
+
+def test_predict_plan_config4_shapes():
+    """BASELINE configs[3]: 8,192 pairs x 3.65 M rows over 2 / 4 / 8 ranks - what each rank allocates and launches."""
+    from mcmc_amd.engine import plan_predict
+    for world, pairs, blocks in ((1, 8192, 14), (2, 4096, 7), (4, 2048, 4), (8, 1024, 2)):
+        plan = plan_predict(8192, 8, 3_650_000, world)
+        assert all(rk.n_local == pairs and rk.hoisted and rk.pairs_per_chunk == pairs for rk in plan.ranks)
+        assert len(plan.row_blocks) == blocks
+        assert plan.n_pilot == 128 and [rk.pilot_share for rk in plan.ranks] == [128] + [0] * (world - 1)
+        ld = (plan.rows_per_block + 63) // 64 * 64
+        assert pairs * ld * 4 <= 8 << 30
+    # weighted shards at world 8 move the boundaries, not the pilot or the blocks
+    w = [1.0, 0.9, 1.1, 1.0, 1.0, 0.95, 1.05, 1.0]
+    plan = plan_predict(8192, 8, 3_650_000, 8, w)
+    assert plan.n_pilot == 128 and plan.ranks[0].pilot_share == 128 and sum(rk.n_local for rk in plan.ranks) == 8192
+    assert max(rk.n_local for rk in plan.ranks) * ((plan.rows_per_block + 63) // 64 * 64) * 4 <= 8 << 30
+
+
 def test_pair_order_is_a_member_interleaved_permutation():
     from mcmc_amd.engine import pair_global_ids
     M, S = 5, 100

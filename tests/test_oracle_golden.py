@@ -45,6 +45,24 @@ def test_predict_cfg1_regenerated_eps_bit_exact(golden):
     assert np.allclose(mean.numpy().astype(np.float64) * float(g["y_scale"]) + float(g["y_mean"]), g["descaled_mean"])
 
 
+def test_predict_trained_members_bit_exact(golden):
+    """main.py:169-170 on the reference itself: members TRAINED by the reference's train() (40 epochs, config-1 series),
+    then its predict() - the oracle must land on it bit for bit, like on the init-time members."""
+    g = golden("predict_trained.npz")
+    M, S = int(g["M"]), int(g["S"])
+    X, mu, rho = (torch.from_numpy(g[k]) for k in ("X", "mu", "rho"))
+    assert float(np.abs(g["rho"] + 3.0).max()) > 0.3 and float(g["preact_absmax"].max()) > 15.0  # not init-time weights
+    eps = orc.reference_rng_eps(int(g["eps_seed"]), M, S, X.shape[1])
+    allp = orc.predict_all(X, mu, rho, eps)
+    assert np.array_equal(allp[:8].numpy(), g["all_predictions_head"])
+    assert np.array_equal(allp[-4:].numpy(), g["all_predictions_tail"])
+    mean, std = orc.reduce_mean_std(allp)
+    assert np.array_equal(mean.numpy(), g["mean"])
+    assert np.array_equal(std.numpy(), g["std"])
+    q = torch.quantile(allp, torch.from_numpy(g["q_levels"]).float(), dim=0)
+    assert np.array_equal(q.numpy(), g["quantiles"])
+
+
 def test_train_mode_masks_bit_exact(golden):
     g = golden("train_fwd.npz")
     X, mu, rho, eps = (torch.from_numpy(g[k]) for k in ("X", "mu", "rho", "eps"))
