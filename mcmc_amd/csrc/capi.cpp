@@ -86,6 +86,22 @@ int mcmc_ctx_create(int device, mcmc_ctx** out) {
     return MCMC_OK;
 }
 
+#ifdef MCMC_DRY_CTX
+// Sanitizer build only (Makefile target `asan`; not declared in include/mcmc_hip.h, not in libmcmc_hip.so): a context without a
+// device, so that every entry point's argument validation is reachable on the CPU box.  Nothing may be launched through it.
+int mcmc_ctx_create_dry(mcmc_ctx** out) {
+    MCMC_REQUIRE(out != nullptr, "out is NULL");
+    mcmc_ctx* c = new (std::nothrow) mcmc_ctx;
+    if (!c) return set_error(MCMC_EHIP, "out of host memory");
+    c->magic = kCtxMagic;
+    c->device = -1;
+    c->num_cu = 256;
+    c->lds_per_block = 160 * 1024;
+    *out = c;
+    return MCMC_OK;
+}
+#endif
+
 int mcmc_ctx_destroy(mcmc_ctx* ctx) {
     if (!ctx || ctx->magic != kCtxMagic) return set_error(MCMC_ESTATE, "invalid or destroyed context");
     ctx->magic = 0;

@@ -23,6 +23,11 @@ int set_error(int code, const char* fmt, ...);
 
 inline int check_ctx(const mcmc_ctx* ctx) {
     if (!ctx || ctx->magic != kCtxMagic) return set_error(MCMC_ESTATE, "invalid or destroyed context");
+#ifdef MCMC_DRY_CTX
+    // `make asan` only (never the product library): a context made by mcmc_ctx_create_dry stands for "some device", so the
+    // argument validation behind this check can run under the host sanitizers on a box without a GPU (tests/abi_check.cpp)
+    if (ctx->device == -1) return MCMC_OK;
+#endif
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return set_error(MCMC_EHIP, "hipGetDevice: %s", hipGetErrorString(e));

@@ -57,17 +57,17 @@ class _PeakWeightedLoss(torch.autograd.Function):
         n = p.numel()
         if (group is False or not _is_dist()) and n >= 1:
             # local statistics (the reference's semantics): one call, loss and gradient together when one will be asked for
-            want_grad = y_pred.requires_grad
+            want_grad = bool(ctx.needs_input_grad[0])
             with torch.cuda.device(eng.device):
                 ws = _workspace(eng)
                 loss = torch.empty(1, dtype=torch.float32, device=eng.device)
                 grad = torch.empty_like(p) if want_grad else None
                 _lib.check(eng.lib.mcmc_loss_fused(eng.ctx.handle, _p(p), _p(t), n, float(alpha), float(beta), 1.0, _p(loss), _p(grad),
                                                    _p(ws), _stream()), "mcmc_loss_fused")
-            ctx.fused_grad = grad
+            ctx.fused, ctx.fused_grad = True, grad
             ctx.meta = (eng, n, n, float(alpha), float(beta), y_pred.shape, y_pred.dtype)
             return loss[0]
-        ctx.fused_grad = None
+        ctx.fused, ctx.fused_grad = False, None
         with torch.cuda.device(eng.device):
             stats = torch.zeros(4, dtype=torch.float64, device=eng.device)
             stats[3] = n
@@ -86,8 +86,9 @@ class _PeakWeightedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         eng, n, n_total, alpha, beta, shape, dtype = ctx.meta
-        if ctx.fused_grad is not None:
-            return (ctx.fused_grad * grad_out.to(torch.float32)).view(shape).to(dtype), None, None, None, None
+        if ctx.fused:  # the one-call path computed the gradient with the loss (or none was asked for: y_true gets no gradient)
+            g = ctx.fused_grad
+            return (None if g is None else (g * grad_out.to(torch.float32)).view(shape).to(dtype)), None, None, None, None
         p, t, stats, part = ctx.saved_tensors
         with torch.cuda.device(eng.device):
             grad = torch.empty_like(p)

@@ -96,11 +96,31 @@ class TemporalFusionTransformer(nn.Module):
         idx = torch.arange(T, device=x.device).repeat(T, 1)      # idx[t] = window order for output timestep t
         t = torch.arange(T, device=x.device)
         idx[t, t], idx[t, T - 1] = T - 1, t                      # rows t and T-1 exchanged
-        windows = x.to(torch.float32)[:, idx, :].reshape(B * T * T, F).contiguous()   # [B, T(out), T(row), F]
-        start = (torch.arange(B * T, device=x.device, dtype=torch.int32) * T)
-        te = TFTEngine(self.flat_parameters().to(x.device), F, T, p_drop=self.p_drop, max_windows=1)
-        out = te.forward(windows, start)
+        te = self._forward_engine(x.device, T)
+        out = torch.empty(B * T, dtype=torch.float32, device=x.device)
+        # the T-fold blow-up of the input ([batch, out timestep, row, feature]) is built for a bounded number of batch items
+        # at a time, and the int32 window starts stay far below 2^31
+        per = max(1, self.FORWARD_WINDOWS // T)
+        xf = x.to(torch.float32)
+        for b0 in range(0, B, per):
+            nb = min(per, B - b0)
+            windows = xf[b0:b0 + nb][:, idx, :].reshape(nb * T * T, F).contiguous()
+            start64 = torch.arange(nb * T, device=x.device, dtype=torch.int64) * T
+            assert nb * T * T < 2 ** 31
+            te.forward(windows, start64.to(torch.int32), out=out[b0 * T:(b0 + nb) * T])
         return out.view(B, T, 1).refine_names("batch", "time", "features")
+
+    FORWARD_WINDOWS = 65536  # windows per launch of forward(): 1.9 M rows x F floats of swapped windows at T = 30
+
+    def _forward_engine(self, device, T: int) -> "TFTEngine":
+        """The engine (device copy of the flat parameters + its transposed image + a context) forward() runs on, rebuilt
+        only when a parameter tensor was replaced, moved or written since the last call (data_ptr / _version)."""
+        key = (str(device), T, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        cached = self.__dict__.get("_fwd_engine")
+        if cached is None or cached[0] != key:
+            cached = (key, TFTEngine(self.flat_parameters().to(device), self.num_features, T, p_drop=self.p_drop, max_windows=1))
+            self.__dict__["_fwd_engine"] = cached
+        return cached[1]
 
 
 @device_guarded

@@ -49,11 +49,15 @@ class EnsembleTrainer:
     # The forward kernel's activations are kept for the backward kernel (autograd's saved tensors) while they fit this many
     # bytes: 1.8 KB per pair and row - 2.9 MB at the reference's 50 pairs x 32 rows, 9.5 GB at 80 pairs x 65,536 rows.
     # Larger batches recompute the forward tile in the backward kernel (the same numbers, ~1.2x the step time).
+    # The bound is the smaller of this constant (constructor argument ``act_max_bytes``) and ACT_FREE_FRACTION of the HBM that
+    # is free when the buffer has to grow; an allocation that fails anyway falls back to the recompute path.
     ACT_MAX_BYTES = 16 << 30
+    ACT_FREE_FRACTION = 0.5
 
     def __init__(self, mu: torch.Tensor, rho: torch.Tensor, input_dim: int, num_samples: int = 10, *, p_drop: float = 0.1,
                  weight_decay: float = 0.01, beta2: float = 0.999, adam_eps: float = 1e-8, max_norm: float = 1.0,
-                 alpha: float = 2.0, beta: float = 0.5):
+                 alpha: float = 2.0, beta: float = 0.5, act_max_bytes: Optional[int] = None):
+        self.act_max_bytes = self.ACT_MAX_BYTES if act_max_bytes is None else int(act_max_bytes)
         self.eng = Engine(mu.device)
         dev = self.eng.device
         self.M, self.P = mu.shape
@@ -100,10 +104,19 @@ class EnsembleTrainer:
             self._delta = self._dbuf[:self.M * rows].view(self.M, rows)
         # saved activations for the backward kernel of small batches (the reference's 32 rows: 2.9 MB for 50 pairs)
         need = pairs * int(self.eng.lib.mcmc_train_act_floats(rows))
-        self._save_act = 4 * need <= self.ACT_MAX_BYTES
+        self._save_act = 4 * need <= self.act_max_bytes
         if self._save_act and (self._act is None or self._act.numel() < need):
             self._act = None  # release before growing
-            self._act = torch.empty(need, dtype=torch.float32, device=self.eng.device)
+            free, _ = torch.cuda.mem_get_info(self.eng.device)
+            if 4 * need > self.ACT_FREE_FRACTION * free:
+                self._save_act = False  # the device is shared (e.g. with mc_predict's 8 GiB sample buffer): recompute instead
+            else:
+                try:
+                    self._act = torch.empty(need, dtype=torch.float32, device=self.eng.device)
+                except torch.cuda.OutOfMemoryError:
+                    self._save_act = False
+        if not self._save_act and self._act is not None and 4 * self._act.numel() > (64 << 20):
+            self._act = None  # a batch too large to save: a big buffer of earlier, smaller batches is handed back
         return self._Y, self._delta
 
     def _buffers(self) -> TrainBuffers:

@@ -319,6 +319,24 @@ def test_loss_alpha_beta_and_large(golden):
     assert np.max(np.abs(pt.grad.cpu().numpy() - g64)) <= 1e-5 * np.max(np.abs(g64))
 
 
+def test_loss_when_only_the_target_requires_grad():
+    """y_true gets no gradient (the reference's callers never ask for one: bayesian_ensemble.py:176, temporal_fusion.py:251);
+    a target that requires grad must not break backward on the one-call path, with or without a gradient for y_pred."""
+    from mcmc_amd import peak_weighted_loss
+    d = _dev()
+    p = torch.randn(64, device=d)
+    t = torch.randn(64, device=d, requires_grad=True)
+    L = peak_weighted_loss(p, t)
+    L.backward()
+    assert t.grad is None and p.grad is None
+    p2 = p.clone().requires_grad_(True)
+    L2 = peak_weighted_loss(p2, t)
+    L2.backward()
+    assert float(L2) == float(L) and p2.grad is not None and t.grad is None
+    _, g64 = orc.peak_weighted_loss_closed_form(p.cpu().numpy(), t.detach().cpu().numpy())
+    assert np.max(np.abs(p2.grad.cpu().numpy() - g64)) <= 2e-6 * max(1e-3, np.max(np.abs(g64)))
+
+
 def test_ensemble_class_contract(golden):
     """Drop-in boundary: named ('batch',) fp32 tensors on the ensemble's device."""
     from mcmc_amd import BayesianNetwork, GPUBayesianEnsemble

@@ -52,6 +52,21 @@ def test_tft_eval_forward_and_predict_match_reference(golden):
     np.testing.assert_allclose(full.rename(None).cpu().numpy(), z["raw_out"], rtol=0, atol=1e-5)
     with pytest.raises(ValueError):
         m.model(torch.zeros(2, 30, F + 1, device=DEV))
+    # forward() keeps its engine while the parameters are untouched, rebuilds it when one is written, and gives the same
+    # numbers when the batch is cut into bounded window chunks
+    eng0 = m.model._forward_engine(DEV, 30)
+    assert m.model._forward_engine(DEV, 30) is eng0
+    try:
+        type(m.model).FORWARD_WINDOWS = 60   # two batch items per launch: 5 items -> 3 launches
+        chunked = m.model(torch.from_numpy(z["raw_batch"]).to(DEV))
+    finally:
+        type(m.model).FORWARD_WINDOWS = 65536
+    assert torch.equal(chunked.rename(None), full.rename(None)) and m.model._forward_engine(DEV, 30) is eng0
+    with torch.no_grad():
+        m.model.output_projection.module.bias.add_(0.25)
+    assert m.model._forward_engine(DEV, 30) is not eng0
+    moved = m.model(torch.from_numpy(z["raw_batch"]).to(DEV))
+    np.testing.assert_allclose(moved.rename(None).cpu().numpy(), z["raw_out"] + 0.25, rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize("step", [0, 1])
