@@ -110,7 +110,7 @@ def test_saved_activations_equal_recompute(rows):
     out = []
     for max_bytes in (EnsembleTrainer.ACT_MAX_BYTES, 0):
         tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
-        tr.ACT_MAX_BYTES = max_bytes
+        tr.act_max_bytes = max_bytes
         losses = [tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, seed=5 + it).clone() for it in range(2)]
         assert tr._save_act == (max_bytes > 0)
         out.append((torch.stack(losses), tr.gmu.clone(), tr.grho.clone(), tr.mu.clone(), tr.rho.clone()))
