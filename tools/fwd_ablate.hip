@@ -22,6 +22,10 @@ int set_error(int code, const char* fmt, ...) {
     fputc('\n', stderr);
     return code;
 }
+int ensure_dyn_lds(const void* kern, size_t bytes, const char* what) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? 0 : set_error(-2, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+}
 }  // namespace mcmc
 
 #define CK(x)                                                                   \
