@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Digest of one tools/gpu_round2.sh session (gpurun_out/round2) into the tracked files under profiles/:
+"""Digest of one tools/gpu_round2.sh / gpu_round3.sh session (gpurun_out/round2, gpurun_out/round3) into the tracked files under profiles/:
 
     python tools/profile_digest.py [gpurun_out/round2] [r02]
 
@@ -11,6 +11,7 @@
   <tag>_pmc_forward.csv / .json    PMC passes over tools/bench_forward.py (--dtype bf16_fast, 3.65 M rows x 256 pairs)
   <tag>_pmc_train.csv              PMC passes over tools/bench_train_kernels.py (65,536 rows x 80 pairs: forward / backward, recomputing and saved)
   <tag>_pmc_reduce.csv / .json     PMC passes over tools/bench_reduce.py (262,144 rows x 8,192 pairs: a bench row block)
+  <tag>_pmc_loss.json              PMC bytes per element and pass of mcmc_loss_fused at 3.65e7 and 4.56e6 elements (round 3 on)
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB; gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md)."""
 import csv
 import glob
@@ -108,6 +109,25 @@ def main():
                    "hbm_bytes_per_launch_measured": hbm, "units_per_launch_measured": units, "hbm_bytes_per_unit": hbm / units,
                    "algorithmic_bytes_per_unit": 4 + 2.0 * (16 + 4 + 256) * 262_144 / units},
                   open(os.path.join(prof, f"{tag}_pmc_reduce.json"), "w"), indent=1)
+    loss = {}
+    for n in (36_500_000, 4_562_500):
+        lp = pmc(os.path.join(src, f"pmc_loss_{n}"), "fused_")
+        if not lp:
+            continue
+        per = {}
+        for kern in ("fused_stats_kernel", "fused_forward_kernel", "fused_backward_kernel"):
+            k = next((k for (k, c) in lp if kern in k and c == "FETCH_SIZE"), None)
+            if k is None:
+                continue
+            fetch, write = lp[(k, "FETCH_SIZE")] * 1024.0, lp.get((k, "WRITE_SIZE"), 0.0) * 1024.0
+            per[kern] = {"FETCH_SIZE_B_per_element": fetch / n, "fetched_B_per_element_corrected": 2 * fetch / n,
+                         "WRITE_SIZE_B_per_element": write / n, "hbm_side_B_per_element": (2 * fetch + write) / n}
+        loss[str(n)] = {"passes": per, "sum_B_per_element": sum(v["hbm_side_B_per_element"] for v in per.values()),
+                        "algorithmic_B_per_element": 20, "moved_by_three_passes_B_per_element": 28,
+                        "note": "FETCH_SIZE doubled (gfx950 reports half the bytes of wide coalesced reads); the counters sit on the L2's "
+                                "memory side, so Infinity-Cache hits are counted: a pass served from the 256 MiB cache still shows its bytes"}
+    if loss:
+        json.dump(loss, open(os.path.join(prof, f"{tag}_pmc_loss.json"), "w"), indent=1)
     print("digest written to profiles/ with tag", tag)
 
 
