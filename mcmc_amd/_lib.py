@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16, DT_BF16_FAST = 0, 1, 2
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class MCMCLibraryError(RuntimeError):
@@ -81,6 +81,8 @@ SIGNATURES = {
                                  _f32, _f32, _f32, _f32, _i64, _ptr, _stream]),
     "mcmc_train_grad": (_i32, [_ctx_p, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _stream]),
     "mcmc_train_row_blocks": (_i32, [_i64]),
+    "mcmc_train_forward_bf16": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _i32, _ptr, _stream]),
+    "mcmc_train_backward_bf16": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _i32, _ptr, _stream]),
     "mcmc_train_backward_blocks": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _i32,
                                           _ptr, _stream]),
     "mcmc_train_apply": (_i32, [_ctx_p, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _f32,

@@ -53,7 +53,7 @@ extern "C" {
 
 const char* mcmc_last_error(void) { return g_err; }
 
-int mcmc_abi_version(void) { return 19; }
+int mcmc_abi_version(void) { return 20; }
 
 int mcmc_ctx_create(int device, mcmc_ctx** out) {
     MCMC_REQUIRE(out != nullptr, "out is NULL");
@@ -471,6 +471,32 @@ int mcmc_train_backward_saved(mcmc_ctx* ctx, const float* xb, int64_t rows, int 
                  "by the tile shape the forward launch chose from it (got %d)", train_row_blocks(rows), row_blocks);
     return train_backward_impl(ctx, xb, rows, input_dim, n_members, n_samples, W, WT, mask_mode, mask0, mask1, mask2, mask_seed, p_drop,
                                delta, row_blocks, dW, act, stream);
+}
+
+int mcmc_train_forward_bf16(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
+                            int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed, float p_drop,
+                            int row_blocks, float* Y, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
+    if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
+    MCMC_REQUIRE(xb && W && Y, "NULL pointer");
+    MCMC_REQUIRE(aligned16(W), "W must be 16-byte aligned");
+    MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
+    return launch_train_forward_bf16(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, mask_mode, mask0, mask1, mask2, mask_seed,
+                                     p_drop, row_blocks, Y, (hipStream_t)stream);
+}
+
+int mcmc_train_backward_bf16(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
+                             int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed, float p_drop,
+                             const float* delta, int row_blocks, float* dW, mcmc_stream_t stream) {
+    if (int rc = check_ctx(ctx)) return rc;
+    if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
+    if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
+    MCMC_REQUIRE(xb && W && delta && dW, "NULL pointer");
+    MCMC_REQUIRE(aligned16(W), "W must be 16-byte aligned");
+    MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
+    return launch_train_backward_bf16(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, mask_mode, mask0, mask1, mask2, mask_seed,
+                                      p_drop, delta, row_blocks, dW, (hipStream_t)stream);
 }
 
 int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }

@@ -56,7 +56,13 @@ class EnsembleTrainer:
 
     def __init__(self, mu: torch.Tensor, rho: torch.Tensor, input_dim: int, num_samples: int = 10, *, p_drop: float = 0.1,
                  weight_decay: float = 0.01, beta2: float = 0.999, adam_eps: float = 1e-8, max_norm: float = 1.0,
-                 alpha: float = 2.0, beta: float = 0.5, act_max_bytes: Optional[int] = None):
+                 alpha: float = 2.0, beta: float = 0.5, act_max_bytes: Optional[int] = None, compute_dtype: str = "fp32"):
+        """``compute_dtype``: "fp32" (default: exact fp32 MFMA, within 2e-5 of the reference's autograd) or "bf16" (opt-in, batches
+        of more than one row block only - 2,048 rows and up: the forward / backward GEMMs on bf16 MFMA operands with fp32
+        accumulation, fp32 master weights and AdamW; loss within 2e-2, gradients within 2e-2 of each tensor's largest entry)."""
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         self.act_max_bytes = self.ACT_MAX_BYTES if act_max_bytes is None else int(act_max_bytes)
         self.eng = Engine(mu.device)
         dev = self.eng.device
@@ -197,8 +203,12 @@ class EnsembleTrainer:
         _lib.check(lib.mcmc_train_sample(h, _p(self.mu), _p(self.sigma), M, S, F, noise_mode, _p(eps), seed & _U64, _p(self.eps),
                                          _p(self.W), _p(self.WT), st), "mcmc_train_sample")
         nb = int(lib.mcmc_train_row_blocks(rows))  # > 1 for large batches: each pair's rows run on nb workgroups
-        save = self._save_act  # the forward pass keeps its activations for the backward kernel (else: recomputed there)
-        if save:
+        bf16 = self.compute_dtype == "bf16" and nb > 1
+        save = self._save_act and not bf16  # the forward pass keeps its activations for the backward kernel (else: recomputed there)
+        if bf16:
+            _lib.check(lib.mcmc_train_forward_bf16(h, _p(xb), rows, F, M, S, _p(self.W), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
+                                                   self.p_drop, nb, _p(Y), st), "mcmc_train_forward_bf16")
+        elif save:
             _lib.check(lib.mcmc_train_forward_save(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
                                                    self.p_drop, _p(Y), _p(self._act), st), "mcmc_train_forward_save")
         else:
@@ -211,7 +221,10 @@ class EnsembleTrainer:
                        "mcmc_train_loss")
         if self.dW.shape[0] < M * S * nb:
             self.dW = torch.empty(M * S * nb, self.P, dtype=torch.float32, device=self.eng.device)
-        if save:
+        if bf16:
+            _lib.check(lib.mcmc_train_backward_bf16(h, _p(xb), rows, F, M, S, _p(self.W), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
+                                                    self.p_drop, _p(delta), nb, _p(self.dW), st), "mcmc_train_backward_bf16")
+        elif save:
             _lib.check(lib.mcmc_train_backward_saved(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2),
                                                      mseed, self.p_drop, _p(delta), nb, _p(self.dW), _p(self._act), st),
                        "mcmc_train_backward_saved")

@@ -51,7 +51,7 @@ int main() {
     const mcmc_stream_t s = nullptr;
 
     // ---- host-only queries, over their whole range ----
-    EXPECT(mcmc_abi_version() >= 19, 1);
+    EXPECT(mcmc_abi_version() >= 20, 1);
     EXPECT(mcmc_last_error() != nullptr, 1);
     for (int F = -2; F <= 40; ++F) {
         const bool ok = F >= 1 && F <= 24;
@@ -130,6 +130,8 @@ int main() {
     ESTATE(mcmc_train_backward(z, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, f, s));
     ESTATE(mcmc_train_backward_blocks(z, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 1, f, s));
     ESTATE(mcmc_train_backward_saved(z, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 1, f, f, s));
+    ESTATE(mcmc_train_forward_bf16(z, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, s));
+    ESTATE(mcmc_train_backward_bf16(z, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 4, f, s));
     ESTATE(mcmc_train_update(z, f, f, f, 1, 1, 11, f, f, f, f, f, f, d, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));
     ESTATE(mcmc_train_grad(z, 1, 1, 1, 11, f, f, f, f, f, d, s));
     ESTATE(mcmc_train_apply(z, f, f, f, 1, 11, f, f, f, f, d, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));
@@ -262,6 +264,13 @@ int main() {
     EXPECT_EINVAL(mcmc_train_backward_blocks(c, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 70000, f, s));
     EXPECT_EINVAL(mcmc_train_backward_saved(c, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 1, f, nullptr, s));
     EXPECT_EINVAL(mcmc_train_backward_saved(c, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 3, f, f, s));   // not the library's split
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 0, f, s));       // row_blocks
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f_odd, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, s));   // W alignment
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 1, u8, u8, nullptr, 0, 0.1f, 4, f, s));
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 25, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, s));
+    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, nullptr, 4, f, s));
+    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 0, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 4, f, s));
+    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 70000, f, s));
     EXPECT_EINVAL(mcmc_train_update(c, f, f, f, 1, 1, 11, f, f, f, f, f, f, d, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 0, nullptr, s));   // step
     EXPECT_EINVAL(mcmc_train_update(c, f, f, f, 1, 1, 11, f, f, f, f, f, f, d, nullptr, 1e-3f, 1.0f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));   // beta1
     EXPECT_EINVAL(mcmc_train_update(c, f, f, f, 1, 1, 11, f, f, f, f, f, f, nullptr, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));

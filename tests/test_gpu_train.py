@@ -118,6 +118,50 @@ def test_saved_activations_equal_recompute(rows):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("F,rows,S,mask", [(11, 2500, 2, "host"), (7, 4200, 1, "host"), (24, 2100, 2, "philox"), (11, 65536, 1, "philox")])
+def test_bf16_large_batch_step_within_2e2(F, rows, S, mask):
+    """Opt-in bf16-operand variant of the large-batch step (mcmc_train_forward_bf16 / mcmc_train_backward_bf16: bf16 MFMA
+    operands, fp32 accumulation, fp32 master weights and AdamW) on the same noise and the same dropout masks: loss within 2e-2 of,
+    every gradient tensor within 2e-2 of its largest entry of, TrainOracle (autograd on the reference's ops, host masks) - and,
+    at the config-5 size with Philox masks (which the oracle's restatement would take minutes to draw), of the fp32 kernels,
+    which the oracle pins at that size in test_train_step_matches_oracle."""
+    from mcmc_amd.train import EnsembleTrainer
+    M = 2
+    mu, rho = _members(F, M, 50 + F)
+    P = orc.n_params(F)
+    xb, yb = _batch(M, rows, F, 400)
+    eps = torch.randn(M, S, P, generator=torch.Generator().manual_seed(401))
+    kw = dict(noise="injected", eps=eps)
+    if mask == "host":
+        kw["masks"] = _masks(M, S, rows, 402)
+    else:
+        kw.update(dropout=True, mask_seed=403)
+    tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S, compute_dtype="bf16")
+    loss = tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, **kw).cpu()
+    gmu, grho = tr.gmu.cpu(), tr.grho.cpu()
+    if mask == "host":
+        ref = []
+        for m in range(M):
+            mk = [mm.view(M, S, rows, -1)[m] for mm in kw["masks"]]
+            L, omu, orho, _ = orc.TrainOracle(mu[m], rho[m]).step(xb[m], yb[m], eps[m], mk, lr=1e-3, beta1=0.9)
+            ref.append((L.detach(), omu, orho))
+    else:
+        t32 = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S)
+        l32 = t32.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, **kw).cpu()
+        ref = [(l32[m], t32.gmu[m].cpu(), t32.grho[m].cpu()) for m in range(M)]
+    for m, (L, omu, orho) in enumerate(ref):
+        assert abs(float(loss[m]) - float(L)) <= 2e-2 * abs(float(L)), (m, float(loss[m]), float(L))
+        for got, want, what in ((gmu[m], omu, "dmu"), (grho[m], orho, "drho")):
+            for (wo, bo, k_in, k_out) in orc.param_offsets(F):  # every tensor against its own largest entry
+                for lo, hi in ((wo, wo + k_in * k_out), (bo, bo + k_out)):
+                    err = float((got[lo:hi] - want[lo:hi]).abs().max())
+                    assert err <= 2e-2 * float(want[lo:hi].abs().max()) + 1e-9, (what, m, lo, err)
+    # the update ran on the bf16 gradients: parameters moved, and by no more than lr per element (AdamW's first step)
+    assert not torch.equal(tr.mu.cpu(), mu) and float((tr.mu.cpu() - mu).abs().max()) <= 1.1e-3
+    with pytest.raises(ValueError):
+        EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S, compute_dtype="fp16")
+
+
 def test_train_replays_reference_trajectory(golden):
     """Both golden members stepped together with the eps / masks / lr / beta1 the reference used."""
     from mcmc_amd.train import EnsembleTrainer
