@@ -266,17 +266,22 @@ int mcmc_train_backward_saved(mcmc_ctx* ctx, const float* xb, int64_t rows, int 
  * 32 rows, bayesian_ensemble.py:124,165-178): the same train-mode forward and back-propagation on bf16 MFMA operands with fp32
  * accumulation; master weights, mcmc_train_sample, mcmc_train_loss, mcmc_train_grad and mcmc_train_apply stay fp32.  fp32 MFMA
  * runs at 1/16 of the bf16 rate, which bounds the fp32 kernels at 10^5 .. 10^6 rows per step.  Reads only W ([out][in] per layer,
- * 16-byte aligned); the backward kernel recomputes each 32-row tile's forward pass (same masks) and writes dW
- * [M*S*row_blocks, P] partials like mcmc_train_backward_blocks.  Y / loss within 2e-2, gradients within 2e-2 of each tensor's
- * largest entry of the fp32 path (tests/test_gpu_train.py). */
+ * 16-byte aligned) and writes dW [M*S*row_blocks, P] partials like mcmc_train_backward_blocks.
+ * act: optional device buffer of n_members*n_samples*mcmc_train_act_bytes_bf16(rows) bytes (16-byte aligned; 0.9 KB per pair
+ * and row): the forward kernel leaves every tile's activations there and the backward kernel reloads them - autograd's saved
+ * tensors, :178; dropped elements are stored as -0.0, so the masks are not drawn again.  NULL in both calls: the backward kernel
+ * recomputes each tile's forward pass with the same masks (same numbers).  Y / loss within 2e-2, gradients within 2e-2 of each
+ * tensor's largest entry of the fp32 path (tests/test_gpu_train.py). */
+int64_t mcmc_train_act_bytes_bf16(int64_t rows);
 int mcmc_train_forward_bf16(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members,
                             int n_samples, const float* W, int mask_mode, const uint8_t* mask0,
                             const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed, float p_drop,
-                            int row_blocks, float* Y, mcmc_stream_t stream);
+                            int row_blocks, float* Y, void* act, mcmc_stream_t stream);
 int mcmc_train_backward_bf16(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members,
                              int n_samples, const float* W, int mask_mode, const uint8_t* mask0,
                              const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed, float p_drop,
-                             const float* delta, int row_blocks, float* dW, mcmc_stream_t stream);
+                             const float* delta, int row_blocks, float* dW, const void* act,
+                             mcmc_stream_t stream);
 /* gmu = sum_s dW, grho = sum_s dW*eps*sigma; clip_grad_norm_(max_norm) per member (:179); AdamW
  * with torch's update rule (:180) on members whose active flag is set (NULL = all); refreshes
  * sigma.  step = 1-based step count for the bias corrections.  adam_m/adam_v: [M,2P] (mu then

@@ -81,8 +81,10 @@ SIGNATURES = {
                                  _f32, _f32, _f32, _f32, _i64, _ptr, _stream]),
     "mcmc_train_grad": (_i32, [_ctx_p, _i32, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _stream]),
     "mcmc_train_row_blocks": (_i32, [_i64]),
-    "mcmc_train_forward_bf16": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _i32, _ptr, _stream]),
-    "mcmc_train_backward_bf16": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _i32, _ptr, _stream]),
+    "mcmc_train_act_bytes_bf16": (_i64, [_i64]),
+    "mcmc_train_forward_bf16": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _i32, _ptr, _ptr, _stream]),
+    "mcmc_train_backward_bf16": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _i32, _ptr, _ptr,
+                                        _stream]),
     "mcmc_train_backward_blocks": (_i32, [_ctx_p, _ptr, _i64, _i32, _i32, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _u64, _f32, _ptr, _i32,
                                           _ptr, _stream]),
     "mcmc_train_apply": (_i32, [_ctx_p, _ptr, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _f32, _f32, _f32, _f32, _f32,

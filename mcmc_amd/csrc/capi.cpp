@@ -475,29 +475,31 @@ int mcmc_train_backward_saved(mcmc_ctx* ctx, const float* xb, int64_t rows, int 
 
 int mcmc_train_forward_bf16(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
                             int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed, float p_drop,
-                            int row_blocks, float* Y, mcmc_stream_t stream) {
+                            int row_blocks, float* Y, void* act, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && W && Y, "NULL pointer");
-    MCMC_REQUIRE(aligned16(W), "W must be 16-byte aligned");
+    MCMC_REQUIRE(aligned16(W) && aligned16(act), "W and act must be 16-byte aligned");
     MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     return launch_train_forward_bf16(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, mask_mode, mask0, mask1, mask2, mask_seed,
-                                     p_drop, row_blocks, Y, (hipStream_t)stream);
+                                     p_drop, row_blocks, Y, act, (hipStream_t)stream);
 }
 
 int mcmc_train_backward_bf16(mcmc_ctx* ctx, const float* xb, int64_t rows, int input_dim, int n_members, int n_samples, const float* W,
                              int mask_mode, const uint8_t* mask0, const uint8_t* mask1, const uint8_t* mask2, uint64_t mask_seed, float p_drop,
-                             const float* delta, int row_blocks, float* dW, mcmc_stream_t stream) {
+                             const float* delta, int row_blocks, float* dW, const void* act, mcmc_stream_t stream) {
     if (int rc = check_ctx(ctx)) return rc;
     if (int rc = check_train(n_members, n_samples, input_dim, rows)) return rc;
     if (int rc = check_masks(mask_mode, mask0, mask1, mask2, p_drop)) return rc;
     MCMC_REQUIRE(xb && W && delta && dW, "NULL pointer");
-    MCMC_REQUIRE(aligned16(W), "W must be 16-byte aligned");
+    MCMC_REQUIRE(aligned16(W) && aligned16(act), "W and act must be 16-byte aligned");
     MCMC_REQUIRE(row_blocks >= 1 && row_blocks <= 65535, "row_blocks must be in [1, 65535] (got %d)", row_blocks);
     return launch_train_backward_bf16(xb, rows * input_dim, rows, input_dim, n_members, n_samples, W, mask_mode, mask0, mask1, mask2, mask_seed,
-                                      p_drop, delta, row_blocks, dW, (hipStream_t)stream);
+                                      p_drop, delta, row_blocks, dW, act, (hipStream_t)stream);
 }
+
+int64_t mcmc_train_act_bytes_bf16(int64_t rows) { return rows < 1 ? 0 : train_act_bytes_bf16(rows); }
 
 int mcmc_train_norm_blocks(void) { return train_grad_blocks(); }
 

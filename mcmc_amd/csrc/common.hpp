@@ -110,10 +110,11 @@ int launch_train_backward(const float* xb, int64_t x_stride, int64_t rows, int F
 // bf16-operand variant of the large-batch forward / backward (train_bf16.hip): W only ([out][in] fp32 from launch_train_sample)
 int launch_train_forward_bf16(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, int mask_mode,
                               const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, int row_blocks,
-                              float* Y, hipStream_t s);
+                              float* Y, void* act, hipStream_t s);
+int64_t train_act_bytes_bf16(int64_t rows);
 int launch_train_backward_bf16(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, int mask_mode,
                                const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                               int row_blocks, float* dW, hipStream_t s);
+                               int row_blocks, float* dW, const void* act, hipStream_t s);
 int launch_train_grad(int M, int S, int row_blocks, int F, const float* eps, const float* sigma, const float* dW, float* gmu,
                       float* grho, double* normsq_part, hipStream_t s);
 int train_row_blocks(int64_t rows);

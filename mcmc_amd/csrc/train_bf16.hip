@@ -99,7 +99,10 @@ __device__ __forceinline__ void store_activation(const f32x16& acc, __bf16* hout
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     float o[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] = acc[i] > 0.0f ? acc[i] : elu_neg(acc[i]);
+    for (int i = 0; i < 16; ++i) {  // both branches evaluated, then a select: no exec-mask branch per element
+        const float e = elu_neg(fminf(acc[i], 0.0f));
+        o[i] = acc[i] > 0.0f ? acc[i] : e;
+    }
     drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row);
     const bool live = row < rows;
 #pragma unroll
@@ -133,19 +136,36 @@ __device__ __forceinline__ void stage_weights(const Lds& l, const float* __restr
     if (t == 0) l.b3[0] = w[flat_b_off(F, 3)];
 }
 
-// forward of one 32-row tile: fills xs, h1, h2, h3 (bf16) and y (fp32)
-template <int MODE>
-__device__ __forceinline__ void forward_tile(const Lds& l, const float* __restrict__ xm, int64_t rows, int F, int64_t row_base, const DropMask& dm,
-                                             int pair) {
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
-    for (int i = t; i < TR * KX; i += NT) {
-        const int rr = i / KX, k = i % KX;
+constexpr int XN = TR * KX / NT;  // input-tile elements per thread
+
+// this thread's elements of the input tile that starts at row_base (column F carries the 1.0 of the layer-0 bias)
+__device__ __forceinline__ void load_x(float (&xr)[XN], const float* __restrict__ xm, int64_t rows, int F, int64_t row_base) {
+#pragma unroll
+    for (int q = 0; q < XN; ++q) {
+        const int i = threadIdx.x + q * NT, rr = i / KX, k = i % KX;
         const int64_t row = row_base + rr;
         float v = 0.0f;
         if (row < rows) v = k < F ? xm[row * F + k] : (k == F ? 1.0f : 0.0f);
-        l.xs[rr * SX + k] = (__bf16)v;
+        xr[q] = v;
     }
+}
+__device__ __forceinline__ void store_x(const Lds& l, const float (&xr)[XN]) {
+#pragma unroll
+    for (int q = 0; q < XN; ++q) {
+        const int i = threadIdx.x + q * NT;
+        l.xs[(i / KX) * SX + i % KX] = (__bf16)xr[q];
+    }
+}
+
+// forward of one 32-row tile: fills xs (from xr), h1, h2, h3 (bf16) and y (fp32); xr is then refilled with the next tile's
+// input rows (next_base >= 0), whose loads land under the layers instead of in front of the next tile
+template <int MODE>
+__device__ __forceinline__ void forward_tile(const Lds& l, float (&xr)[XN], const float* __restrict__ xm, int64_t rows, int F, int64_t row_base,
+                                             int64_t next_base, const DropMask& dm, int pair) {
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
+    store_x(l, xr);
     __syncthreads();
+    if (next_base >= 0) load_x(xr, xm, rows, F, next_base);
     const int64_t row = row_base + r;
     {  // layer 0: 8 units, one per wave; the bias rides on input column F
         f32x16 acc = {0};
@@ -191,20 +211,36 @@ __device__ __forceinline__ void block_rows(int64_t rows, int64_t& begin, int64_t
     end = begin + per < rows ? begin + per : rows;
 }
 
+// h1 | h2 | h3 of a tile are contiguous in LDS: the forward kernel can leave them in `act` (29.5 KB per pair and 32 rows) for the
+// backward kernel, which then neither recomputes the forward pass nor draws the masks again (dropped elements are -0.0)
+constexpr int kActElems = TR * (S1 + S2 + S3);
+static_assert((kActElems * 2) % 16 == 0, "activation tiles are copied as 16-byte pieces");
+constexpr int AN = (kActElems * 2 / 16 + NT - 1) / NT;  // 16-byte pieces per thread
+
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void train_forward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
-                                                                  const float* __restrict__ W, DropMask dm, float* __restrict__ Y) {
+                                                                  const float* __restrict__ W, DropMask dm, float* __restrict__ Y,
+                                                                  uint4* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S;
     int64_t begin, end;
     block_rows(rows, begin, end);
     if (begin >= end) return;
+    const float* xm = xb + (int64_t)m * x_stride;
+    float xr[XN];
+    load_x(xr, xm, rows, F, begin);
     stage_weights(l, W + (int64_t)pair * flat_param_count(F), F);
     __syncthreads();
+    const int64_t tiles = (rows + TR - 1) / TR;
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, dm, pair);
+        forward_tile<MODE>(l, xr, xm, rows, F, row_base, row_base + TR < end ? row_base + TR : -1, dm, pair);
         if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
+        if (act) {
+            uint4* dst = act + ((int64_t)pair * tiles + row_base / TR) * (kActElems * 2 / 16);
+            const uint4* src = reinterpret_cast<const uint4*>(l.h1);
+            for (int i = threadIdx.x; i < kActElems * 2 / 16; i += NT) dst[i] = src[i];
+        }
         __syncthreads();
     }
 }
@@ -229,7 +265,7 @@ __device__ __forceinline__ void input_grad_unit(const __bf16* Wimg, int sw, int 
 template <int MODE>
 __global__ __launch_bounds__(NT, 2) void train_backward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
                                                                    const float* __restrict__ W, DropMask dm, const float* __restrict__ delta,
-                                                                   float* __restrict__ dW) {
+                                                                   float* __restrict__ dW, const uint4* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S, t = threadIdx.x;
@@ -242,6 +278,18 @@ __global__ __launch_bounds__(NT, 2) void train_backward_bf16_kernel(const float*
         for (int64_t i = t; i < P; i += NT) g[i] = 0.0f;
         return;
     }
+    const float* xm = xb + (int64_t)m * x_stride;
+    const int64_t tiles = (rows + TR - 1) / TR;
+    float xr[XN];
+    uint4 ar[AN];  // the next tile's saved activations, in flight under the current tile's arithmetic
+    auto load_act = [&](int64_t row_base) {
+        const uint4* src = act + ((int64_t)pair * tiles + row_base / TR) * (kActElems * 2 / 16);
+#pragma unroll
+        for (int q = 0; q < AN; ++q)
+            if (t + q * NT < kActElems * 2 / 16) ar[q] = src[t + q * NT];
+    };
+    load_x(xr, xm, rows, F, begin);
+    if (act) load_act(begin);
     stage_weights(l, W + (int64_t)pair * P, F);
     __syncthreads();
     const float sc = MODE != 0 ? dm.scale : 1.0f;
@@ -251,7 +299,21 @@ __global__ __launch_bounds__(NT, 2) void train_backward_bf16_kernel(const float*
     for (int mo = 0; mo < H2 / 32; ++mo) gw1[mo] = f32x16{0};
     float gcol = 0.0f;  // thread t: db1[t] (t < 128), db2[t - 128] (t < 192), dw3[t - 192] (t < 256), db3 (t == 256)
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, xb + (int64_t)m * x_stride, rows, F, row_base, dm, pair);
+        const int64_t next_base = row_base + TR < end ? row_base + TR : -1;
+        if (act) {  // the forward kernel saved this tile's h1 | h2 | h3: no recompute, no masks
+            store_x(l, xr);
+            uint4* dst = reinterpret_cast<uint4*>(l.h1);
+#pragma unroll
+            for (int q = 0; q < AN; ++q)
+                if (t + q * NT < kActElems * 2 / 16) dst[t + q * NT] = ar[q];
+            __syncthreads();
+            if (next_base >= 0) {
+                load_x(xr, xm, rows, F, next_base);
+                load_act(next_base);
+            }
+        } else {
+            forward_tile<MODE>(l, xr, xm, rows, F, row_base, next_base, dm, pair);
+        }
         // ---- layer 3: dy; dw3, db3; dz2 = dy * w3 * d(h3) over h3
         if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
         __syncthreads();
@@ -347,22 +409,25 @@ DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const uint8_t
 
 int launch_train_forward_bf16(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, int mask_mode,
                               const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, int row_blocks,
-                              float* Y, hipStream_t s) {
+                              float* Y, void* act, hipStream_t s) {
     auto kern = MCMC_TB_PICK(train_forward_bf16_kernel, mask_mode);
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), kLdsBytes, "train_forward_bf16")) return rc;
     hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), kLdsBytes, s, xb, x_stride, rows, F, S, W,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y);
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), Y, reinterpret_cast<uint4*>(act));
     return check_launch("train_forward_bf16");
 }
 
 int launch_train_backward_bf16(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, int mask_mode,
                                const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
-                               int row_blocks, float* dW, hipStream_t s) {
+                               int row_blocks, float* dW, const void* act, hipStream_t s) {
     auto kern = MCMC_TB_PICK(train_backward_bf16_kernel, mask_mode);
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), kLdsBytes, "train_backward_bf16")) return rc;
     hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), kLdsBytes, s, xb, x_stride, rows, F, S, W,
-                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW);
+                       make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, reinterpret_cast<const uint4*>(act));
     return check_launch("train_backward_bf16");
 }
+
+// bytes per pair of the bf16 saved-activation buffer for a batch of `rows` rows
+int64_t train_act_bytes_bf16(int64_t rows) { return (rows + TR - 1) / TR * (int64_t)kActElems * 2; }
 
 }  // namespace mcmc

@@ -125,6 +125,24 @@ class EnsembleTrainer:
             self._act = None  # a batch too large to save: a big buffer of earlier, smaller batches is handed back
         return self._Y, self._delta
 
+    def _act_bf16(self, rows: int) -> Optional[torch.Tensor]:
+        """Saved-activation buffer of the bf16 variant (0.9 KB per pair and row), under the same bounds as the fp32 one."""
+        need = self.M * self.S * int(self.eng.lib.mcmc_train_act_bytes_bf16(rows))
+        buf = getattr(self, "_act16", None)
+        if need > self.act_max_bytes:
+            self._act16 = None
+            return None
+        if buf is None or buf.numel() < need:
+            self._act16 = None
+            free, _ = torch.cuda.mem_get_info(self.eng.device)
+            if need > self.ACT_FREE_FRACTION * free:
+                return None
+            try:
+                self._act16 = torch.empty(need, dtype=torch.uint8, device=self.eng.device)
+            except torch.cuda.OutOfMemoryError:
+                return None
+        return self._act16
+
     def _buffers(self) -> TrainBuffers:
         """mcmc_train_buffers of the current allocations (rebuilt when any tensor was re-allocated or re-bound)."""
         key = tuple(t.data_ptr() for t in (self.mu, self.rho, self.sigma, self.eps, self.W, self.WT, self.dW, self.gmu, self.grho,
@@ -206,8 +224,9 @@ class EnsembleTrainer:
         bf16 = self.compute_dtype == "bf16" and nb > 1
         save = self._save_act and not bf16  # the forward pass keeps its activations for the backward kernel (else: recomputed there)
         if bf16:
+            act16 = self._act_bf16(rows)  # saved bf16 activations (None: the backward kernel recomputes)
             _lib.check(lib.mcmc_train_forward_bf16(h, _p(xb), rows, F, M, S, _p(self.W), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
-                                                   self.p_drop, nb, _p(Y), st), "mcmc_train_forward_bf16")
+                                                   self.p_drop, nb, _p(Y), _p(act16), st), "mcmc_train_forward_bf16")
         elif save:
             _lib.check(lib.mcmc_train_forward_save(h, _p(xb), rows, F, M, S, _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
                                                    self.p_drop, _p(Y), _p(self._act), st), "mcmc_train_forward_save")
@@ -223,7 +242,7 @@ class EnsembleTrainer:
             self.dW = torch.empty(M * S * nb, self.P, dtype=torch.float32, device=self.eng.device)
         if bf16:
             _lib.check(lib.mcmc_train_backward_bf16(h, _p(xb), rows, F, M, S, _p(self.W), mask_mode, _p(m0), _p(m1), _p(m2), mseed,
-                                                    self.p_drop, _p(delta), nb, _p(self.dW), st), "mcmc_train_backward_bf16")
+                                                    self.p_drop, _p(delta), nb, _p(self.dW), _p(act16), st), "mcmc_train_backward_bf16")
         elif save:
             _lib.check(lib.mcmc_train_backward_saved(h, _p(xb), rows, F, M, S, _p(self.W), _p(self.WT), mask_mode, _p(m0), _p(m1), _p(m2),
                                                      mseed, self.p_drop, _p(delta), nb, _p(self.dW), _p(self._act), st),

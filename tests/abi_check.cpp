@@ -82,6 +82,8 @@ int main() {
     EXPECT(mcmc_train_row_blocks(2047), 1);
     EXPECT(mcmc_train_row_blocks(65536) > 1 && mcmc_train_row_blocks(65536) <= 64, 1);
     EXPECT(mcmc_train_row_blocks((int64_t)1 << 40) <= 64, 1);
+    EXPECT(mcmc_train_act_bytes_bf16(0), 0);
+    EXPECT(mcmc_train_act_bytes_bf16(65536) > 0 && mcmc_train_act_bytes_bf16(65536) % 16 == 0, 1);
     EXPECT(mcmc_train_act_floats(0), 0);
     EXPECT(mcmc_train_act_floats(-3), 0);
     EXPECT(mcmc_train_act_floats(32) > 0, 1);
@@ -130,8 +132,8 @@ int main() {
     ESTATE(mcmc_train_backward(z, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, f, s));
     ESTATE(mcmc_train_backward_blocks(z, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 1, f, s));
     ESTATE(mcmc_train_backward_saved(z, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 1, f, f, s));
-    ESTATE(mcmc_train_forward_bf16(z, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, s));
-    ESTATE(mcmc_train_backward_bf16(z, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 4, f, s));
+    ESTATE(mcmc_train_forward_bf16(z, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, nullptr, s));
+    ESTATE(mcmc_train_backward_bf16(z, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 4, f, nullptr, s));
     ESTATE(mcmc_train_update(z, f, f, f, 1, 1, 11, f, f, f, f, f, f, d, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));
     ESTATE(mcmc_train_grad(z, 1, 1, 1, 11, f, f, f, f, f, d, s));
     ESTATE(mcmc_train_apply(z, f, f, f, 1, 11, f, f, f, f, d, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));
@@ -264,13 +266,14 @@ int main() {
     EXPECT_EINVAL(mcmc_train_backward_blocks(c, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 70000, f, s));
     EXPECT_EINVAL(mcmc_train_backward_saved(c, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 1, f, nullptr, s));
     EXPECT_EINVAL(mcmc_train_backward_saved(c, f, 4, 11, 1, 1, f, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 3, f, f, s));   // not the library's split
-    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 0, f, s));       // row_blocks
-    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f_odd, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, s));   // W alignment
-    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 1, u8, u8, nullptr, 0, 0.1f, 4, f, s));
-    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 25, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, s));
-    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, nullptr, 4, f, s));
-    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 0, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 4, f, s));
-    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 70000, f, s));
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 0, f, nullptr, s));       // row_blocks
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f_odd, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, nullptr, s));   // W alignment
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, f_odd, s));   // act alignment
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 11, 1, 1, f, 1, u8, u8, nullptr, 0, 0.1f, 4, f, nullptr, s));
+    EXPECT_EINVAL(mcmc_train_forward_bf16(c, f, 4096, 25, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, 4, f, nullptr, s));
+    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, nullptr, 4, f, nullptr, s));
+    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 0, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 4, f, nullptr, s));
+    EXPECT_EINVAL(mcmc_train_backward_bf16(c, f, 4096, 11, 1, 1, f, 0, nullptr, nullptr, nullptr, 0, 0.1f, f, 70000, f, nullptr, s));
     EXPECT_EINVAL(mcmc_train_update(c, f, f, f, 1, 1, 11, f, f, f, f, f, f, d, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 0, nullptr, s));   // step
     EXPECT_EINVAL(mcmc_train_update(c, f, f, f, 1, 1, 11, f, f, f, f, f, f, d, nullptr, 1e-3f, 1.0f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));   // beta1
     EXPECT_EINVAL(mcmc_train_update(c, f, f, f, 1, 1, 11, f, f, f, f, f, f, nullptr, nullptr, 1e-3f, 0.9f, 0.999f, 1e-8f, 0.01f, 1.0f, 1, nullptr, s));

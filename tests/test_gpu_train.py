@@ -162,6 +162,25 @@ def test_bf16_large_batch_step_within_2e2(F, rows, S, mask):
         EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S, compute_dtype="fp16")
 
 
+@pytest.mark.parametrize("rows,mask", [(2500, "philox"), (4128, "none")])
+def test_bf16_saved_activations_equal_recompute(rows, mask):
+    """bf16 variant: the backward kernel that reloads the forward kernel's bf16 activation tiles (act) == the one that
+    recomputes them (act NULL): the same bf16 operands reach the same MFMAs, so loss, gradients and parameters agree bit for bit."""
+    from mcmc_amd.train import EnsembleTrainer
+    F, M, S = 11, 2, 3
+    mu, rho = _members(F, M, 8)
+    xb, yb = _batch(M, rows, F, 78)
+    kw = dict(dropout=True, mask_seed=9) if mask == "philox" else dict(dropout=False)
+    out = []
+    for max_bytes in (None, 0):
+        tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S, compute_dtype="bf16", act_max_bytes=max_bytes)
+        losses = [tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, seed=5 + it, **kw).clone() for it in range(2)]
+        assert (getattr(tr, "_act16", None) is not None) == (max_bytes is None)
+        out.append((torch.stack(losses), tr.gmu.clone(), tr.grho.clone(), tr.mu.clone(), tr.rho.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 def test_train_replays_reference_trajectory(golden):
     """Both golden members stepped together with the eps / masks / lr / beta1 the reference used."""
     from mcmc_amd.train import EnsembleTrainer

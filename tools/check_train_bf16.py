@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--mask", default="philox")
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--no-save", action="store_true", help="bf16: recompute the forward pass in the backward kernel")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(1)
@@ -34,7 +35,7 @@ def main():
     yb = (torch.randn(a.M, a.rows, generator=g) + (torch.rand(a.M, a.rows, generator=g) > 0.85).float() * 2.0).to(dev)
     res = {}
     for dt in ("fp32", "bf16"):
-        tr = EnsembleTrainer(mu.to(dev), rho.to(dev), a.F, a.S, compute_dtype=dt)
+        tr = EnsembleTrainer(mu.to(dev), rho.to(dev), a.F, a.S, compute_dtype=dt, act_max_bytes=0 if (a.no_save and dt == "bf16") else None)
         kw = dict(seed=7, dropout=(a.mask == "philox"))
         if a.mask == "host":
             gm = torch.Generator().manual_seed(3)
