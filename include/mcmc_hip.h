@@ -116,8 +116,10 @@ int mcmc_forward(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows, in
  * :158; an opt-in MC-dropout predict - the reference's predict() itself runs in eval mode): the
  * keep flag of hidden activation elem (0..447 over the three layers) of global pair id
  * g = (q % n_members) * n_samples + q / n_members, q = pair_begin + c, and batch row `row` is
- * u01(Philox4x32-10(counter (elem>>2, g, 'MASK', row_begin + row), key mask_seed)[elem&3]) < 1 - p_drop:
- * the stream of mcmc_train_forward's mask_mode 2, so predict and train see the same masks.
+ * a 16-bit half of Philox4x32-10(counter (((elem>>4)<<1) | ((elem>>2)&1), g, 'MASK', row_begin + row),
+ * key mask_seed) - half slot&1 of output word slot>>1, slot = 4*((elem>>3)&1) + (elem&3) - compared
+ * < floor((1 - p_drop) * 65536): one Philox block per eight elements (ABI 21; 32 bits per element
+ * before).  It is the stream of mcmc_train_forward's mask_mode 2: predict and train see the same masks.
  * row_begin: global index of the launch's first row (0 unless the launch is one row block of a
  * larger input: the masks then do not depend on how the rows are cut into launches). */
 int mcmc_forward_dropout(mcmc_ctx* ctx, int dtype, const void* xpack, int64_t n_rows,

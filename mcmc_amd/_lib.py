@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MCMC_LIB_PATH") or os.path.join(_HERE, "lib", "libmcm
 
 DT_F32, DT_BF16, DT_BF16_FAST = 0, 1, 2
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 class MCMCLibraryError(RuntimeError):

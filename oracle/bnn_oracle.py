@@ -282,19 +282,24 @@ def philox_keep_masks(seed: int, pair: int, rows: int, p_drop: float = P_DROP, r
     """Dropout keep-masks [rows,256],[rows,128],[rows,64] of one pair from the 'MASK' Philox stream, for the global rows
     row_begin .. row_begin + rows - 1.
 
-    Counter = (elem>>2, pair, 0x4D41534B ['MASK'], row), key = seed; component elem&3;
-    elem runs over the 448 hidden activations (256 | 128 | 64); keep iff u01 < 1-p (fp32 compare).
-    Same keying as mcmc_amd/csrc/philox.hpp:philox_mask_uniform / train.hip:keep_flag.
+    16 bits per element: one Philox block serves eight elements.  elem runs over the 448 hidden activations
+    (256 | 128 | 64); counter = (((elem>>4)<<1) | ((elem>>2)&1), pair, 0x4D41534B ['MASK'], row), key = seed;
+    slot = 4*((elem>>3)&1) + (elem&3) selects the 16-bit half slot&1 of output word slot>>1;
+    keep iff that half < floor(fp32(1-p) * 65536).  Same definition as mcmc_amd/csrc/dropmask.hpp:drop16.
     """
     n_el = sum(HIDDEN)
     row = (np.arange(rows, dtype=np.int64) + row_begin).astype(np.uint32)[:, None]
     elem = np.arange(n_el, dtype=np.uint32)[None, :]
     row, elem = np.broadcast_arrays(row, elem)
-    ctr = np.stack([elem >> np.uint32(2), np.full_like(elem, pair), np.full_like(elem, 0x4D41534B), row], axis=-1)
+    blk = ((elem >> np.uint32(4)) << np.uint32(1)) | ((elem >> np.uint32(2)) & np.uint32(1))
+    slot = ((elem >> np.uint32(3)) & np.uint32(1)) * np.uint32(4) + (elem & np.uint32(3))
+    ctr = np.stack([blk, np.full_like(elem, pair), np.full_like(elem, 0x4D41534B), row], axis=-1)
     key = np.stack([np.full_like(elem, seed & 0xFFFFFFFF), np.full_like(elem, (seed >> 32) & 0xFFFFFFFF)], axis=-1)
     x = philox4x32_10(ctr, key)
-    u = _u01(np.take_along_axis(x, (elem & np.uint32(3)).astype(np.int64)[..., None], axis=-1)[..., 0])
-    keep = (u < np.float32(1.0 - p_drop)).astype(np.uint8)
+    word = np.take_along_axis(x, (slot >> np.uint32(1)).astype(np.int64)[..., None], axis=-1)[..., 0]
+    half = (word >> (np.uint32(16) * (slot & np.uint32(1)))) & np.uint32(0xFFFF)
+    thr = np.uint32(int(np.float32(np.float32(1.0) - np.float32(p_drop)) * np.float32(65536.0)))
+    keep = (half < thr).astype(np.uint8)
     a, b = HIDDEN[0], HIDDEN[0] + HIDDEN[1]
     return keep[:, :a], keep[:, a:b], keep[:, b:]
 

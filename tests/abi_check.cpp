@@ -51,7 +51,7 @@ int main() {
     const mcmc_stream_t s = nullptr;
 
     // ---- host-only queries, over their whole range ----
-    EXPECT(mcmc_abi_version() >= 20, 1);
+    EXPECT(mcmc_abi_version() >= 21, 1);
     EXPECT(mcmc_last_error() != nullptr, 1);
     for (int F = -2; F <= 40; ++F) {
         const bool ok = F >= 1 && F <= 24;
