@@ -6,19 +6,24 @@
 // (/root/reference/models/bayesian_ensemble.py:165-178) like train_tiles.hpp does, with bf16 GEMM operands: fp32 MFMA runs
 // at the vector rate (1/16 of the bf16 rate), and at 10^5 .. 10^6 rows per step the fp32 kernels are bound by it.
 //
-// One workgroup (8 waves) = one pair x one row block.  The pair's effective weights (W = mu + eps * sigma, fp32 [out][in] from
-// mcmc_train_sample) are converted once into bf16 row-major LDS images; the activations of a 32-row tile live in LDS as bf16
-// [row][feature] tiles and are turned into the gradients w.r.t. their pre-activations in place, as in the fp32 kernels.
-// Every GEMM of the step reads its operands from those images with one of two fragment loaders:
+// One workgroup (16 waves, four per SIMD) = one pair x one row block, 64 rows at a time.  The pair's effective weights
+// (W = mu + eps * sigma, fp32 [out][in] from mcmc_train_sample) of layers 1 and 2 are converted once into bf16 row-major LDS
+// images (layer 0's 256 x (F+1) sit in the registers of the wave that multiplies by them); the activations of a 64-row tile live
+// in LDS as bf16 [row][feature] tiles and are turned into the gradients w.r.t. their pre-activations in place, as in the fp32
+// kernels.  Every GEMM of the step reads its operands from those images with one of two fragment loaders:
 //   row fragment  (ds_read_b128):          lane (r, h) <- T[row0 + r][k0 + 8h .. 8h+7]        A = W rows, B = activation rows
 //   transposed    (2 x ds_read_b64_tr_b16): lane (r, h) <- T[k0 + 8h .. 8h+7][col0 + r]        the same tiles read column-wise
 //   forward      Z^T[out, row]  = W[out, k]       . H[row, k]        A row(W),   B row(H)
 //   input grad   dH^T[in, row]  = W^T[in, out]    . dZ[row, out]     A tr(W),    B row(dZ)
 //   weight grad  dW[out, in]   += dZ^T[out, row]  . H[row, in]       A tr(dZ),   B tr(H)
-// so no tile is stored twice.  The weight gradients of a row block stay in accumulator registers across its tiles (96 per
-// lane: wave w owns dW1[:, 32w .. 32w+31], one 32 x 32 tile of dW2 and one of dW0) and are written once, as the block's
-// partial dW[pair * row_blocks + block] in the flat layout, for mcmc_train_grad to sum.  ELU, dropout masks (host or the
-// 'MASK' Philox stream, dropmask.hpp) and the -0.0 marking of dropped elements are those of the fp32 kernels.
+// so no tile is stored twice.  The phases between two workgroup barriers are sized so that the 64 waves-per-CU-worth of MFMAs
+// of the wide layers run together: the weight gradient of a layer and the input gradient that follows it only READ the tiles, so
+// they share a phase, and the in-place epilogue that overwrites the activations with the next gradient is the phase after.
+// The weight gradients of a row block stay in accumulator registers across its tiles (48 per lane: wave w owns two 32 x 32
+// tiles of dW1 and one of dW2 (w < 8) or dW0 (w >= 8)) and are written once, as the block's partial
+// dW[pair * row_blocks + block] in the flat layout, for mcmc_train_grad to sum; bias and output-layer gradients are per-thread
+// partial sums reduced across the workgroup at the end of the block.  ELU, dropout masks (host or the 'MASK' Philox stream,
+// dropmask.hpp) and the -0.0 marking of dropped elements are those of the fp32 kernels.
 #include "common.hpp"
 #include "dropmask.hpp"
 #include "elu.hpp"
@@ -29,29 +34,30 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-constexpr int NT = 512, NW = 8, TR = 32;
+constexpr int NT = 1024, NW = 16, TR = 64;
 constexpr int KX = 32;  // width of the input tile: input columns, then the 1.0 that carries the layer-0 bias (F <= 24)
 // row strides in bf16 elements: +8 keeps rows 16-byte aligned and spreads ds_read_b128 row reads over all banks
-constexpr int SW0 = KX + 8, SW1 = H1 + 8, SW2 = H2 + 8;           // weight images  [256][SW0], [128][SW1], [64][SW2]
+constexpr int SW1 = H1 + 8, SW2 = H2 + 8;                          // weight images  [128][SW1], [64][SW2]
 constexpr int SX = KX + 8, S1 = H1 + 8, S2 = H2 + 8, S3 = H3 + 8;  // activation tiles [TR][...]
 constexpr int kSmallFloats = H2 + H3 + H3 + 4;                     // b1 | b2 | w3 | b3 (fp32)
-constexpr size_t kLdsBytes = 2 * (size_t)(H1 * SW0 + H2 * SW1 + H3 * SW2 + TR * (SX + S1 + S2 + S3)) + 4 * (kSmallFloats + TR);
+constexpr size_t kLdsBytes = 2 * (size_t)(H2 * SW1 + H3 * SW2 + TR * (SX + S1 + S2 + S3)) + 4 * (kSmallFloats + TR);
+static_assert(kLdsBytes <= 160 * 1024, "one workgroup per CU");
 
 struct Lds {
-    __bf16 *w0, *w1, *w2;      // weight images
+    __bf16 *w1, *w2;            // weight images
     __bf16 *xs, *h1, *h2, *h3;  // tiles
-    float *b1, *b2, *w3, *b3;  // fp32
-    float* y;                  // [TR] outputs, then dLoss/dy
+    float *b1, *b2, *w3, *b3;   // fp32
+    float* y;                   // [TR] dLoss/dy of the tile
 };
 
 __device__ __forceinline__ Lds carve(unsigned char* base) {
     Lds l;
-    l.w0 = reinterpret_cast<__bf16*>(base);
-    l.w1 = l.w0 + H1 * SW0;
+    l.w1 = reinterpret_cast<__bf16*>(base);
     l.w2 = l.w1 + H2 * SW1;
     l.xs = l.w2 + H3 * SW2;
     l.h1 = l.xs + TR * SX;
@@ -68,20 +74,27 @@ __device__ __forceinline__ Lds carve(unsigned char* base) {
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 acc) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); }
 
 // lane (r, h) <- T[row0 + r][k0 + 8h .. +7]
-__device__ __forceinline__ bf16x8 row_frag(const __bf16* T, int stride, int row0, int k0) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ bf16x8 row_frag(int lane, const __bf16* T, int stride, int row0, int k0) {
     return *reinterpret_cast<const bf16x8*>(T + (row0 + (lane & 31)) * stride + k0 + 8 * (lane >> 5));
 }
 
 // lane (r, h) <- T[k0 + 8h + j][col0 + r], j = 0..7: per 16-lane group two 4-row x 16-column blocks read column-major
 // (ds_read_b64_tr_b16: lane 4q+p of a group supplies the address of block row q, columns 4p .. 4p+3, and receives column
 // (lane & 15) of the four rows).  EXEC must be all ones: callers keep these reads out of lane-divergent code.
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16* T, int stride, int k0, int col0) {
-    const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+__device__ __forceinline__ bf16x8 tr_frag(int lane, const __bf16* T, int stride, int k0, int col0) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const __bf16* a = T + (k0 + 8 * (g >> 1) + q) * stride + col0 + 16 * (g & 1) + 4 * p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * stride));
     return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+
+// The lane id, opaque to the optimiser: addresses derived from it are computed where they are used instead of being hoisted out
+// of the tile loop, where two dozen of them would stay live beside the accumulators (128 registers per lane at 16 waves).
+__device__ __forceinline__ int fresh_lane() {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    return lane;
 }
 
 // derivative factor d = elu'(z) * mask * scale recovered from the stored activation (train.hip:dfactor)
@@ -90,13 +103,12 @@ __device__ __forceinline__ float dfactor(float h, float scale) {
     return h > 0.0f ? scale : h + scale;
 }
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// activation epilogue of one 32 x 32 forward unit: ELU, dropout, bf16, into hout[row][32 mo + feature]
+// activation epilogue of one 32 x 32 forward unit (feature tile mo, row tile rt): ELU, dropout, bf16, into hout[row][32 mo + feature]
 template <int MODE>
-__device__ __forceinline__ void store_activation(const f32x16& acc, __bf16* hout, int stride, int mo, const DropMask& dm, int layer, int pair,
-                                                 int64_t rows, int64_t row) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void store_activation(const f32x16& acc, __bf16* hout, int stride, int mo, int rt, const DropMask& dm, int layer,
+                                                 int pair, int64_t rows, int64_t row_base) {
+    const int lane = fresh_lane(), r = lane & 31, h = lane >> 5;
+    const int64_t row = row_base + 32 * rt + r;
     float o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {  // both branches evaluated, then a select: no exec-mask branch per element
@@ -110,30 +122,44 @@ __device__ __forceinline__ void store_activation(const f32x16& acc, __bf16* hout
         bf16x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (__bf16)(live ? o[4 * q + j] : -0.0f);
-        *reinterpret_cast<bf16x4*>(hout + r * stride + 32 * mo + 8 * q + 4 * h) = v;
+        *reinterpret_cast<bf16x4*>(hout + (32 * rt + r) * stride + 32 * mo + 8 * q + 4 * h) = v;
     }
 }
 
-// the pair's weights -> bf16 LDS images (once per workgroup)
+// the pair's layer-1 / layer-2 weights -> bf16 LDS images, biases and the output layer -> fp32 (once per workgroup)
 __device__ __forceinline__ void stage_weights(const Lds& l, const float* __restrict__ w, int F) {
     const int t = threadIdx.x;
-    for (int i = t; i < H1 * KX; i += NT) {
-        const int o = i / KX, k = i % KX;
-        const float v = k < F ? w[flat_w_off(F, 0) + (int64_t)o * F + k] : k == F ? w[flat_b_off(F, 0) + o] : 0.0f;
-        l.w0[o * SW0 + k] = (__bf16)v;
-    }
     for (int i = t; i < H2 * H1 / 4; i += NT) {
         const int o = i / (H1 / 4), k = 4 * (i % (H1 / 4));
         const float4 v = *reinterpret_cast<const float4*>(w + flat_w_off(F, 1) + (int64_t)o * H1 + k);
         *reinterpret_cast<bf16x4*>(l.w1 + o * SW1 + k) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
     }
-    for (int i = t; i < H3 * H2; i += NT) l.w2[(i / H2) * SW2 + i % H2] = (__bf16)w[flat_w_off(F, 2) + i];
-    for (int i = t; i < H2; i += NT) l.b1[i] = w[flat_b_off(F, 1) + i];
-    for (int i = t; i < H3; i += NT) {
-        l.b2[i] = w[flat_b_off(F, 2) + i];
-        l.w3[i] = w[flat_w_off(F, 3) + i];
+    for (int i = t; i < H3 * H2 / 4; i += NT) {
+        const int o = i / (H2 / 4), k = 4 * (i % (H2 / 4));
+        const float4 v = *reinterpret_cast<const float4*>(w + flat_w_off(F, 2) + (int64_t)o * H2 + k);
+        *reinterpret_cast<bf16x4*>(l.w2 + o * SW2 + k) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
     }
-    if (t == 0) l.b3[0] = w[flat_b_off(F, 3)];
+    if (t < H2) l.b1[t] = w[flat_b_off(F, 1) + t];
+    else if (t < H2 + H3) l.b2[t - H2] = w[flat_b_off(F, 2) + t - H2];
+    else if (t < H2 + 2 * H3) l.w3[t - H2 - H3] = w[flat_w_off(F, 3) + t - H2 - H3];
+    else if (t == H2 + 2 * H3) l.b3[0] = w[flat_b_off(F, 3)];
+}
+
+// layer 0 as the A fragments of one output tile: lane (r, h) <- [W0 | b0 | 0][32 ot + r][16 s + 8h .. +7]
+struct W0Frag {
+    bf16x8 a[2];
+};
+__device__ __forceinline__ W0Frag load_w0(const float* __restrict__ w, int F, int ot) {
+    const int lane = threadIdx.x & 63, o = 32 * ot + (lane & 31), h = lane >> 5;
+    W0Frag f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            f.a[s][j] = (__bf16)(k < F ? w[flat_w_off(F, 0) + (int64_t)o * F + k] : k == F ? w[flat_b_off(F, 0) + o] : 0.0f);
+        }
+    return f;
 }
 
 constexpr int XN = TR * KX / NT;  // input-tile elements per thread
@@ -157,42 +183,46 @@ __device__ __forceinline__ void store_x(const Lds& l, const float (&xr)[XN]) {
     }
 }
 
-// forward of one 32-row tile: fills xs (from xr), h1, h2, h3 (bf16) and y (fp32); xr is then refilled with the next tile's
-// input rows (next_base >= 0), whose loads land under the layers instead of in front of the next tile
+// forward of one 64-row tile: fills xs (from xr), h1, h2, h3 (bf16); writes the outputs to Y (when given); xr is then refilled
+// with the next tile's input rows (next_base >= 0), whose loads land under the layers instead of in front of the next tile.
+// Four barriers; the tiles are complete after the third, and callers must put a barrier between this call and the next write
+// of xs / h1 (the next call's own first barrier does that for a loop of calls).
 template <int MODE>
-__device__ __forceinline__ void forward_tile(const Lds& l, float (&xr)[XN], const float* __restrict__ xm, int64_t rows, int F, int64_t row_base,
-                                             int64_t next_base, const DropMask& dm, int pair) {
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
+__device__ __forceinline__ void forward_tile(const Lds& l, const W0Frag& w0, float (&xr)[XN], const float* __restrict__ xm, int64_t rows, int F,
+                                             int64_t row_base, int64_t next_base, const DropMask& dm, int pair, float* __restrict__ Ypair) {
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5;
     store_x(l, xr);
     __syncthreads();
     if (next_base >= 0) load_x(xr, xm, rows, F, next_base);
-    const int64_t row = row_base + r;
-    {  // layer 0: 8 units, one per wave; the bias rides on input column F
+    {  // layer 0: 8 feature tiles x 2 row tiles, one unit per wave; the bias rides on input column F
+        const int mo = wave & 7, rt = wave >> 3, ln = fresh_lane();
         f32x16 acc = {0};
-        const int ks0 = (F + 1 + 15) / 16;
-        for (int s = 0; s < ks0; ++s) acc = mfma16(row_frag(l.w0, SW0, 32 * wave, 16 * s), row_frag(l.xs, SX, 0, 16 * s), acc);
-        store_activation<MODE>(acc, l.h1, S1, wave, dm, 0, pair, rows, row);
+        acc = mfma16(w0.a[0], row_frag(ln, l.xs, SX, 32 * rt, 0), acc);
+        if (F + 1 > 16) acc = mfma16(w0.a[1], row_frag(ln, l.xs, SX, 32 * rt, 16), acc);
+        store_activation<MODE>(acc, l.h1, S1, mo, rt, dm, 0, pair, rows, row_base);
     }
     __syncthreads();
-    if (wave < H2 / 32) {  // layer 1: 4 units
+    if (wave < 2 * (H2 / 32)) {  // layer 1: 4 x 2 units
+        const int mo = wave & 3, rt = wave >> 2, ln = fresh_lane();
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = l.b1[32 * wave + acc_feature(i, h)];
+        for (int i = 0; i < 16; ++i) acc[i] = l.b1[32 * mo + acc_feature(i, h)];
 #pragma unroll 4
-        for (int s = 0; s < H1 / 16; ++s) acc = mfma16(row_frag(l.w1, SW1, 32 * wave, 16 * s), row_frag(l.h1, S1, 0, 16 * s), acc);
-        store_activation<MODE>(acc, l.h2, S2, wave, dm, 1, pair, rows, row);
+        for (int s = 0; s < H1 / 16; ++s) acc = mfma16(row_frag(ln, l.w1, SW1, 32 * mo, 16 * s), row_frag(ln, l.h1, S1, 32 * rt, 16 * s), acc);
+        store_activation<MODE>(acc, l.h2, S2, mo, rt, dm, 1, pair, rows, row_base);
     }
     __syncthreads();
-    if (wave < H3 / 32) {  // layer 2: 2 units
+    if (wave < 2 * (H3 / 32)) {  // layer 2: 2 x 2 units
+        const int mo = wave & 1, rt = wave >> 1, ln = fresh_lane();
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = l.b2[32 * wave + acc_feature(i, h)];
+        for (int i = 0; i < 16; ++i) acc[i] = l.b2[32 * mo + acc_feature(i, h)];
 #pragma unroll 4
-        for (int s = 0; s < H2 / 16; ++s) acc = mfma16(row_frag(l.w2, SW2, 32 * wave, 16 * s), row_frag(l.h2, S2, 0, 16 * s), acc);
-        store_activation<MODE>(acc, l.h3, S3, wave, dm, 2, pair, rows, row);
+        for (int s = 0; s < H2 / 16; ++s) acc = mfma16(row_frag(ln, l.w2, SW2, 32 * mo, 16 * s), row_frag(ln, l.h2, S2, 32 * rt, 16 * s), acc);
+        store_activation<MODE>(acc, l.h3, S3, mo, rt, dm, 2, pair, rows, row_base);
     }
     __syncthreads();
-    if (t < 8 * TR) {  // layer 3: 64 -> 1, eight threads per row
+    if (Ypair && t < 8 * TR) {  // layer 3: 64 -> 1, eight threads per row
         const int rr = t >> 3, part = t & 7;
         float a = 0.0f;
 #pragma unroll
@@ -200,9 +230,8 @@ __device__ __forceinline__ void forward_tile(const Lds& l, float (&xr)[XN], cons
         a += __shfl_xor(a, 1);
         a += __shfl_xor(a, 2);
         a += __shfl_xor(a, 4);
-        if (part == 0) l.y[rr] = a + l.b3[0];
+        if (part == 0 && row_base + rr < rows) Ypair[row_base + rr] = a + l.b3[0];
     }
-    __syncthreads();
 }
 
 __device__ __forceinline__ void block_rows(int64_t rows, int64_t& begin, int64_t& end) {
@@ -211,16 +240,17 @@ __device__ __forceinline__ void block_rows(int64_t rows, int64_t& begin, int64_t
     end = begin + per < rows ? begin + per : rows;
 }
 
-// h1 | h2 | h3 of a tile are contiguous in LDS: the forward kernel can leave them in `act` (29.5 KB per pair and 32 rows) for the
+// h1 | h2 | h3 of a tile are contiguous in LDS: the forward kernel can leave them in `act` (59 KB per pair and 64 rows) for the
 // backward kernel, which then neither recomputes the forward pass nor draws the masks again (dropped elements are -0.0)
 constexpr int kActElems = TR * (S1 + S2 + S3);
 static_assert((kActElems * 2) % 16 == 0, "activation tiles are copied as 16-byte pieces");
-constexpr int AN = (kActElems * 2 / 16 + NT - 1) / NT;  // 16-byte pieces per thread
+constexpr int kActPieces = kActElems * 2 / 16;
+constexpr int AN = (kActPieces + NT - 1) / NT;  // 16-byte pieces per thread
 
 template <int MODE>
-__global__ __launch_bounds__(NT, 2) void train_forward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
-                                                                  const float* __restrict__ W, DropMask dm, float* __restrict__ Y,
-                                                                  uint4* __restrict__ act) {
+__global__ __launch_bounds__(NT) void train_forward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
+                                                               const float* __restrict__ W, DropMask dm, float* __restrict__ Y,
+                                                               uint4* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S;
@@ -228,32 +258,37 @@ __global__ __launch_bounds__(NT, 2) void train_forward_bf16_kernel(const float* 
     block_rows(rows, begin, end);
     if (begin >= end) return;
     const float* xm = xb + (int64_t)m * x_stride;
+    const float* w = W + (int64_t)pair * flat_param_count(F);
     float xr[XN];
     load_x(xr, xm, rows, F, begin);
-    stage_weights(l, W + (int64_t)pair * flat_param_count(F), F);
+    const W0Frag w0 = load_w0(w, F, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 7);
+    stage_weights(l, w, F);
     __syncthreads();
     const int64_t tiles = (rows + TR - 1) / TR;
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, xr, xm, rows, F, row_base, row_base + TR < end ? row_base + TR : -1, dm, pair);
-        if (threadIdx.x < TR && row_base + threadIdx.x < rows) Y[(int64_t)pair * rows + row_base + threadIdx.x] = l.y[threadIdx.x];
-        if (act) {
-            uint4* dst = act + ((int64_t)pair * tiles + row_base / TR) * (kActElems * 2 / 16);
+        forward_tile<MODE>(l, w0, xr, xm, rows, F, row_base, row_base + TR < end ? row_base + TR : -1, dm, pair, Y + (int64_t)pair * rows);
+        if (act) {  // the tiles are complete; the next tile's first barrier comes before anything overwrites them
+            uint4* dst = act + ((int64_t)pair * tiles + row_base / TR) * kActPieces;
             const uint4* src = reinterpret_cast<const uint4*>(l.h1);
-            for (int i = threadIdx.x; i < kActElems * 2 / 16; i += NT) dst[i] = src[i];
+            for (int i = threadIdx.x; i < kActPieces; i += NT) dst[i] = src[i];
         }
-        __syncthreads();
     }
 }
 
-// dH^T[in tile mi, rows] = W^T . dZ, times d(h_in), written over h_in in place: one 32 x 32 unit
-__device__ __forceinline__ void input_grad_unit(const __bf16* Wimg, int sw, int OUT, const __bf16* dz, int sdz, __bf16* hin, int sin, int mi,
-                                                float scale) {
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+// dH^T[in tile mi, row tile rt] = W^T . dZ: the MFMA chain (reads only)
+__device__ __forceinline__ f32x16 input_grad_mfma(const __bf16* Wimg, int sw, int OUT, const __bf16* dz, int sdz, int mi, int rt) {
+    const int ln = fresh_lane();
     f32x16 acc = {0};
-    for (int s = 0; s < OUT / 16; ++s) acc = mfma16(tr_frag(Wimg, sw, 16 * s, 32 * mi), row_frag(dz, sdz, 0, 16 * s), acc);
+#pragma unroll 2
+    for (int s = 0; s < OUT / 16; ++s) acc = mfma16(tr_frag(ln, Wimg, sw, 16 * s, 32 * mi), row_frag(ln, dz, sdz, 32 * rt, 16 * s), acc);
+    return acc;
+}
+// ... times d(h_in), written over h_in in place
+__device__ __forceinline__ void input_grad_store(const f32x16& acc, __bf16* hin, int sin, int mi, int rt, float scale) {
+    const int lane = fresh_lane(), r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        bf16x4* p = reinterpret_cast<bf16x4*>(hin + r * sin + 32 * mi + 8 * q + 4 * h);
+        bf16x4* p = reinterpret_cast<bf16x4*>(hin + (32 * rt + r) * sin + 32 * mi + 8 * q + 4 * h);
         const bf16x4 hv = *p;
         bf16x4 o;
 #pragma unroll
@@ -262,10 +297,12 @@ __device__ __forceinline__ void input_grad_unit(const __bf16* Wimg, int sw, int 
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(NT, 2) void train_backward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
-                                                                   const float* __restrict__ W, DropMask dm, const float* __restrict__ delta,
-                                                                   float* __restrict__ dW, const uint4* __restrict__ act) {
+// SAVED: the forward kernel left the tiles in `act`; otherwise each tile's forward pass is recomputed here (two builds, so that
+// neither carries the other's registers: 128 per lane at four waves per SIMD)
+template <int MODE, bool SAVED>
+__global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
+                                                                const float* __restrict__ W, DropMask dm, const float* __restrict__ delta,
+                                                                float* __restrict__ dW, const uint4* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lds l = carve(smem);
     const int pair = blockIdx.x, m = pair / S, t = threadIdx.x;
@@ -279,113 +316,168 @@ __global__ __launch_bounds__(NT, 2) void train_backward_bf16_kernel(const float*
         return;
     }
     const float* xm = xb + (int64_t)m * x_stride;
+    const float* w = W + (int64_t)pair * P;
+    const float* dm_row = delta + (int64_t)m * rows;
     const int64_t tiles = (rows + TR - 1) / TR;
     float xr[XN];
-    uint4 ar[AN];  // the next tile's saved activations, in flight under the current tile's arithmetic
-    auto load_act = [&](int64_t row_base) {
-        const uint4* src = act + ((int64_t)pair * tiles + row_base / TR) * (kActElems * 2 / 16);
-#pragma unroll
-        for (int q = 0; q < AN; ++q)
-            if (t + q * NT < kActElems * 2 / 16) ar[q] = src[t + q * NT];
+    float dyr = 0.0f;  // t < TR: dLoss/dy of this thread's row of the next tile
+    // Saved activations: a register prefetch of the next tile (16 registers per lane) does not fit beside the accumulators at four
+    // waves per SIMD, so each thread touches one 128-byte line of the next tile instead (one register, consumed at the next
+    // phase A): the tile's own loads then hit L2.
+    float touch = 0.0f;
+    auto touch_act = [&](int64_t row_base) {
+        if (!SAVED) return;
+        const char* src = reinterpret_cast<const char*>(act + ((int64_t)pair * tiles + row_base / TR) * kActPieces);
+        if (t < (kActPieces * 16 + 127) / 128) touch = *reinterpret_cast<const float*>(src + 128 * t);
+    };
+    auto load_dy = [&](int64_t row_base) {
+        if (t < TR) dyr = row_base + t < rows ? dm_row[row_base + t] : 0.0f;
     };
     load_x(xr, xm, rows, F, begin);
-    if (act) load_act(begin);
-    stage_weights(l, W + (int64_t)pair * P, F);
+    load_dy(begin);
+    W0Frag w0 = {};
+    if (!SAVED) w0 = load_w0(w, F, wave & 7);
+    stage_weights(l, w, F);
     __syncthreads();
     const float sc = MODE != 0 ? dm.scale : 1.0f;
-    // the block's weight gradients, in registers across its tiles
-    f32x16 gw1[H2 / 32], gw2 = {0}, gw0 = {0};
-#pragma unroll
-    for (int mo = 0; mo < H2 / 32; ++mo) gw1[mo] = f32x16{0};
-    float gcol = 0.0f;  // thread t: db1[t] (t < 128), db2[t - 128] (t < 192), dw3[t - 192] (t < 256), db3 (t == 256)
+    // the block's weight gradients, in registers across its tiles:
+    //   gw1[j]: dW1[out tile 2 (wave >> 3) + j][in tile wave & 7];  gwx: dW2[out tile wave >> 2][in tile wave & 3] (wave < 8),
+    //   dW0 | db0 [out tile wave - 8] (wave >= 8)
+    f32x16 gw1[2] = {f32x16{0}, f32x16{0}}, gwx = {0};
+    // per-thread partial sums: column t & 63 of dw3 and db2 over the rows this thread visits, db3 (lanes with column 0),
+    // column t & 127 of db1 over a quarter of the rows (t < 512)
+    float g_w3 = 0.0f, g_b2 = 0.0f, g_b3 = 0.0f, g_b1 = 0.0f;
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         const int64_t next_base = row_base + TR < end ? row_base + TR : -1;
-        if (act) {  // the forward kernel saved this tile's h1 | h2 | h3: no recompute, no masks
+        // ---- phase A: the tile's x, h1 | h2 | h3 and dy in LDS
+        if (SAVED) {  // the forward kernel saved this tile's h1 | h2 | h3: no recompute, no masks
+            const uint4* src = act + ((int64_t)pair * tiles + row_base / TR) * kActPieces;
+            uint4 a[AN];
+#pragma unroll
+            for (int q = 0; q < AN; ++q) a[q] = t + q * NT < kActPieces ? src[t + q * NT] : uint4{0, 0, 0, 0};
             store_x(l, xr);
+            if (t < TR) l.y[t] = dyr;
             uint4* dst = reinterpret_cast<uint4*>(l.h1);
 #pragma unroll
             for (int q = 0; q < AN; ++q)
-                if (t + q * NT < kActElems * 2 / 16) dst[t + q * NT] = ar[q];
+                if (t + q * NT < kActPieces) dst[t + q * NT] = a[q];
+            asm volatile("" ::"v"(touch));
             __syncthreads();
             if (next_base >= 0) {
                 load_x(xr, xm, rows, F, next_base);
-                load_act(next_base);
+                load_dy(next_base);
+                touch_act(next_base);
             }
         } else {
-            forward_tile<MODE>(l, xr, xm, rows, F, row_base, next_base, dm, pair);
+            forward_tile<MODE>(l, w0, xr, xm, rows, F, row_base, next_base, dm, pair, nullptr);
+            if (t < TR) l.y[t] = dyr;
+            __syncthreads();
+            if (next_base >= 0) load_dy(next_base);
         }
-        // ---- layer 3: dy; dw3, db3; dz2 = dy * w3 * d(h3) over h3
-        if (t < TR) l.y[t] = row_base + t < rows ? delta[(int64_t)m * rows + row_base + t] : 0.0f;
+        // ---- phase B: output layer.  dw3 += dy h3, db3 += dy; dz2 = dy w3 d(h3) over h3, db2 += dz2
+        {
+            const int k = t & 63;
+            const float w3k = l.w3[k];
+#pragma unroll
+            for (int j = 0; j < TR / NW; ++j) {
+                const int rr = wave + NW * j;
+                const float yv = l.y[rr];
+                const float hv = (float)l.h3[rr * S3 + k];
+                g_w3 = fmaf(yv, hv, g_w3);
+                g_b3 += yv;
+                const float dz = yv * w3k * dfactor(hv, sc);
+                g_b2 += dz;
+                l.h3[rr * S3 + k] = (__bf16)dz;
+            }
+        }
         __syncthreads();
-        if (t >= H2 + H3 && t < H2 + H3 + H3) {
-            const int k = t - (H2 + H3);
+        // ---- phase C: dW2 += dz2^T h2 (waves 0-7)  |  the MFMA chain of dz1 = W2^T dz2 (waves 8-15)
+        f32x16 ig = {0};
+        if (wave < 8) {
+            const int ln = fresh_lane();
+#pragma unroll
+            for (int ks = 0; ks < TR / 16; ++ks)
+                gwx = mfma16(tr_frag(ln, l.h3, S3, 16 * ks, 32 * (wave >> 2)), tr_frag(ln, l.h2, S2, 16 * ks, 32 * (wave & 3)), gwx);
+        } else {
+            ig = input_grad_mfma(l.w2, SW2, H3, l.h3, S3, (wave - 8) & 3, (wave - 8) >> 2);
+        }
+        __syncthreads();
+        // ---- phase D: dz1 over h2
+        if (wave >= 8) input_grad_store(ig, l.h2, S2, (wave - 8) & 3, (wave - 8) >> 2, sc);
+        __syncthreads();
+        // ---- phase E: dW1 += dz1^T h1, and the MFMA chain of dz0 = W1^T dz1 (all waves; both only read the tiles)
+        {
+            const int ln = fresh_lane();
+#pragma unroll 1
+            for (int ks = 0; ks < TR / 16; ++ks) {
+                const bf16x8 b = tr_frag(ln, l.h1, S1, 16 * ks, 32 * (wave & 7));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) gw1[j] = mfma16(tr_frag(ln, l.h2, S2, 16 * ks, 32 * (2 * (wave >> 3) + j)), b, gw1[j]);
+            }
+        }
+        ig = input_grad_mfma(l.w1, SW1, H2, l.h2, S2, wave & 7, wave >> 3);
+        __syncthreads();
+        // ---- phase F: dz0 over h1
+        input_grad_store(ig, l.h1, S1, wave & 7, wave >> 3, sc);
+        __syncthreads();
+        // ---- phase G: dW0 | db0 (column F of the input tile is 1) += dz0^T x (waves 8-15)  |  db1 += column sums of dz1 (waves 0-7)
+        if (wave >= 8) {
+            const int ln = fresh_lane();
+#pragma unroll
+            for (int ks = 0; ks < TR / 16; ++ks) gwx = mfma16(tr_frag(ln, l.h1, S1, 16 * ks, 32 * (wave - 8)), tr_frag(ln, l.xs, SX, 16 * ks, 0), gwx);
+        } else {
+            const int col = t & (H2 - 1), r0 = (t >> 7) * (TR / 4);
             float a = 0.0f;
 #pragma unroll 8
-            for (int rr = 0; rr < TR; ++rr) a = fmaf(l.y[rr], (float)l.h3[rr * S3 + k], a);
-            gcol += a;
-        } else if (t == H2 + H3 + H3) {
-            float a = 0.0f;
-            for (int rr = 0; rr < TR; ++rr) a += l.y[rr];
-            gcol += a;
+            for (int rr = 0; rr < TR / 4; ++rr) a += (float)l.h2[(r0 + rr) * S2 + col];
+            g_b1 += a;
         }
-        __syncthreads();
-        for (int i = t; i < TR * H3; i += NT) {
-            const int rr = i / H3, k = i % H3;
-            const float hv = (float)l.h3[rr * S3 + k];
-            l.h3[rr * S3 + k] = (__bf16)(l.y[rr] * l.w3[k] * dfactor(hv, sc));
-        }
-        __syncthreads();
-        // ---- layer 2: dW2 += dz2^T h2 (wave w: out tile w >> 2, in tile w & 3); db2; then dz1 over h2
-#pragma unroll
-        for (int ks = 0; ks < TR / 16; ++ks)
-            gw2 = mfma16(tr_frag(l.h3, S3, 16 * ks, 32 * (wave >> 2)), tr_frag(l.h2, S2, 16 * ks, 32 * (wave & 3)), gw2);
-        if (t >= H2 && t < H2 + H3) {
-            float a = 0.0f;
-#pragma unroll 8
-            for (int rr = 0; rr < TR; ++rr) a += (float)l.h3[rr * S3 + t - H2];
-            gcol += a;
-        }
-        __syncthreads();
-        if (wave < H2 / 32) input_grad_unit(l.w2, SW2, H3, l.h3, S3, l.h2, S2, wave, sc);
-        __syncthreads();
-        // ---- layer 1: dW1[:, in tile w] += dz1^T h1; db1; then dz0 over h1
-#pragma unroll
-        for (int ks = 0; ks < TR / 16; ++ks) {
-            const bf16x8 b = tr_frag(l.h1, S1, 16 * ks, 32 * wave);
-#pragma unroll
-            for (int mo = 0; mo < H2 / 32; ++mo) gw1[mo] = mfma16(tr_frag(l.h2, S2, 16 * ks, 32 * mo), b, gw1[mo]);
-        }
-        if (t < H2) {
-            float a = 0.0f;
-#pragma unroll 8
-            for (int rr = 0; rr < TR; ++rr) a += (float)l.h2[rr * S2 + t];
-            gcol += a;
-        }
-        __syncthreads();
-        input_grad_unit(l.w1, SW1, H2, l.h2, S2, l.h1, S1, wave, sc);
-        __syncthreads();
-        // ---- layer 0: dW0 | db0 (column F of the input tile is 1) += dz0^T x  (wave w: out tile w)
-#pragma unroll
-        for (int ks = 0; ks < TR / 16; ++ks) gw0 = mfma16(tr_frag(l.h1, S1, 16 * ks, 32 * wave), tr_frag(l.xs, SX, 16 * ks, 0), gw0);
         __syncthreads();
     }
     // ---- the block's partial, flat layout: register i of lane (r, h) holds [out = 32 tile + acc_feature(i, h)][in = 32 tile + r]
 #pragma unroll
-    for (int mo = 0; mo < H2 / 32; ++mo)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) g[flat_w_off(F, 1) + (int64_t)(32 * mo + acc_feature(i, h)) * H1 + 32 * wave + r] = gw1[mo][i];
+        for (int i = 0; i < 16; ++i)
+            g[flat_w_off(F, 1) + (int64_t)(32 * (2 * (wave >> 3) + j) + acc_feature(i, h)) * H1 + 32 * (wave & 7) + r] = gw1[j][i];
+    if (wave < 8) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) g[flat_w_off(F, 2) + (int64_t)(32 * (wave >> 2) + acc_feature(i, h)) * H2 + 32 * (wave & 3) + r] = gw2[i];
+        for (int i = 0; i < 16; ++i) g[flat_w_off(F, 2) + (int64_t)(32 * (wave >> 2) + acc_feature(i, h)) * H2 + 32 * (wave & 3) + r] = gwx[i];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int o = 32 * wave + acc_feature(i, h);
-        if (r < F) g[flat_w_off(F, 0) + (int64_t)o * F + r] = gw0[i];
-        else if (r == F) g[flat_b_off(F, 0) + o] = gw0[i];
+        for (int i = 0; i < 16; ++i) {
+            const int o = 32 * (wave - 8) + acc_feature(i, h);
+            if (r < F) g[flat_w_off(F, 0) + (int64_t)o * F + r] = gwx[i];
+            else if (r == F) g[flat_b_off(F, 0) + o] = gwx[i];
+        }
     }
-    if (t < H2) g[flat_b_off(F, 1) + t] = gcol;
-    else if (t < H2 + H3) g[flat_b_off(F, 2) + t - H2] = gcol;
-    else if (t < H2 + H3 + H3) g[flat_w_off(F, 3) + t - (H2 + H3)] = gcol;
-    else if (t == H2 + H3 + H3) g[flat_b_off(F, 3)] = gcol;
+    // per-thread partial sums -> LDS (the h1 tile is free: the loop ended on a barrier) -> one thread per element
+    float* red = reinterpret_cast<float*>(l.h1);  // [NW][64] dw3 | [NW][64] db2 | [NW] db3 | [4][128] db1
+    float* red_w3 = red;
+    float* red_b2 = red_w3 + NW * H3;
+    float* red_b3 = red_b2 + NW * H3;
+    float* red_b1 = red_b3 + NW;
+    static_assert((2 * NW * H3 + NW + 4 * H2) * 4 <= TR * S1 * 2, "reduction scratch fits the h1 tile");
+    red_w3[wave * H3 + lane] = g_w3;
+    red_b2[wave * H3 + lane] = g_b2;
+    if (lane == 0) red_b3[wave] = g_b3;
+    if (t < 4 * H2) red_b1[t] = g_b1;
+    __syncthreads();
+    if (t < H2) {
+        g[flat_b_off(F, 1) + t] = red_b1[t] + red_b1[H2 + t] + red_b1[2 * H2 + t] + red_b1[3 * H2 + t];
+    } else if (t < H2 + H3) {
+        float a = 0.0f;
+        for (int v = 0; v < NW; ++v) a += red_b2[v * H3 + t - H2];
+        g[flat_b_off(F, 2) + t - H2] = a;
+    } else if (t < H2 + 2 * H3) {
+        float a = 0.0f;
+        for (int v = 0; v < NW; ++v) a += red_w3[v * H3 + t - H2 - H3];
+        g[flat_w_off(F, 3) + t - H2 - H3] = a;
+    } else if (t == H2 + 2 * H3) {
+        float a = 0.0f;
+        for (int v = 0; v < NW; ++v) a += red_b3[v];
+        g[flat_b_off(F, 3)] = a;
+    }
 }
 
 DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t seed, float p_drop) {
@@ -420,7 +512,8 @@ int launch_train_forward_bf16(const float* xb, int64_t x_stride, int64_t rows, i
 int launch_train_backward_bf16(const float* xb, int64_t x_stride, int64_t rows, int F, int M, int S, const float* W, int mask_mode,
                                const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t mask_seed, float p_drop, const float* delta,
                                int row_blocks, float* dW, const void* act, hipStream_t s) {
-    auto kern = MCMC_TB_PICK(train_backward_bf16_kernel, mask_mode);
+    auto kern = act ? (mask_mode == 1 ? train_backward_bf16_kernel<1, true> : mask_mode == 2 ? train_backward_bf16_kernel<2, true> : train_backward_bf16_kernel<0, true>)
+                    : (mask_mode == 1 ? train_backward_bf16_kernel<1, false> : mask_mode == 2 ? train_backward_bf16_kernel<2, false> : train_backward_bf16_kernel<0, false>);
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), kLdsBytes, "train_backward_bf16")) return rc;
     hipLaunchKernelGGL(kern, dim3(M * S, row_blocks), dim3(NT), kLdsBytes, s, xb, x_stride, rows, F, S, W,
                        make_mask(mask_mode, m0, m1, m2, mask_seed, p_drop), delta, dW, reinterpret_cast<const uint4*>(act));
