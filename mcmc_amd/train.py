@@ -53,6 +53,9 @@ class EnsembleTrainer:
     # is free when the buffer has to grow; an allocation that fails anyway falls back to the recompute path.
     ACT_MAX_BYTES = 16 << 30
     ACT_FREE_FRACTION = 0.5
+    # bf16 kernels: cost model of _bf16_row_blocks in rows (a block's fixed cost; one more partial in the gradient sum)
+    BF16_BLOCK_COST_ROWS = 256
+    BF16_PARTIAL_COST_ROWS = 128
 
     def __init__(self, mu: torch.Tensor, rho: torch.Tensor, input_dim: int, num_samples: int = 10, *, p_drop: float = 0.1,
                  weight_decay: float = 0.01, beta2: float = 0.999, adam_eps: float = 1e-8, max_norm: float = 1.0,
@@ -63,6 +66,7 @@ class EnsembleTrainer:
         if compute_dtype not in ("fp32", "bf16"):
             raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
         self.compute_dtype = compute_dtype
+        self.bf16_row_blocks = 0  # 0: chosen by _bf16_row_blocks; a positive value pins it (measurements)
         self.act_max_bytes = self.ACT_MAX_BYTES if act_max_bytes is None else int(act_max_bytes)
         self.eng = Engine(mu.device)
         dev = self.eng.device
@@ -124,6 +128,28 @@ class EnsembleTrainer:
         if not self._save_act and self._act is not None and 4 * self._act.numel() > (64 << 20):
             self._act = None  # a batch too large to save: a big buffer of earlier, smaller batches is handed back
         return self._Y, self._delta
+
+    def _bf16_row_blocks(self, rows: int) -> int:
+        """Row blocks per pair for the bf16 kernels (one 16-wave workgroup per CU, 64-row tiles; any count is valid): the count
+        that minimises (rounds of workgroups over the CUs) x (rows per block + a block's fixed cost: weight staging, the
+        write of its dW partial) + the gradient sum's read of one partial per block."""
+        if self.bf16_row_blocks:
+            return int(self.bf16_row_blocks)
+        key = (rows, self.M * self.S)
+        if getattr(self, "_nb16_key", None) == key:
+            return self._nb16
+        cus = torch.cuda.get_device_properties(self.eng.device).multi_processor_count
+        best, best_cost = 1, None
+        for nb in range(1, 65):
+            per = -(-(-(-rows // nb)) // 64) * 64
+            if (nb - 1) * per >= rows:
+                continue  # would leave empty blocks
+            rounds = -(-(self.M * self.S * nb) // cus)
+            cost = rounds * (per + self.BF16_BLOCK_COST_ROWS) + self.BF16_PARTIAL_COST_ROWS * nb
+            if best_cost is None or cost < best_cost:
+                best, best_cost = nb, cost
+        self._nb16_key, self._nb16 = key, best
+        return best
 
     def _act_bf16(self, rows: int) -> Optional[torch.Tensor]:
         """Saved-activation buffer of the bf16 variant (0.9 KB per pair and row), under the same bounds as the fp32 one."""
@@ -222,6 +248,8 @@ class EnsembleTrainer:
                                          _p(self.W), _p(self.WT), st), "mcmc_train_sample")
         nb = int(lib.mcmc_train_row_blocks(rows))  # > 1 for large batches: each pair's rows run on nb workgroups
         bf16 = self.compute_dtype == "bf16" and nb > 1
+        if bf16:
+            nb = self._bf16_row_blocks(rows)
         save = self._save_act and not bf16  # the forward pass keeps its activations for the backward kernel (else: recomputed there)
         if bf16:
             act16 = self._act_bf16(rows)  # saved bf16 activations (None: the backward kernel recomputes)

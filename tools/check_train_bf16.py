@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--mask", default="philox")
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--nb", type=int, default=0, help="bf16: pin the row blocks per pair")
     ap.add_argument("--no-save", action="store_true", help="bf16: recompute the forward pass in the backward kernel")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -36,6 +37,7 @@ def main():
     res = {}
     for dt in ("fp32", "bf16"):
         tr = EnsembleTrainer(mu.to(dev), rho.to(dev), a.F, a.S, compute_dtype=dt, act_max_bytes=0 if (a.no_save and dt == "bf16") else None)
+        tr.bf16_row_blocks = a.nb
         kw = dict(seed=7, dropout=(a.mask == "philox"))
         if a.mask == "host":
             gm = torch.Generator().manual_seed(3)
@@ -54,6 +56,8 @@ def main():
             torch.cuda.synchronize()
             ms = sorted(x.elapsed_time(y) for x, y in evs)[2]
             flop = 3 * 2 * (a.F * 256 + 256 * 128 + 128 * 64 + 64) * a.M * a.S * a.rows
+            if dt == "bf16":
+                print("row blocks per pair:", tr._bf16_row_blocks(a.rows))
             print(f"{dt}: {ms:.3f} ms per step  {flop / ms / 1e9:.1f} TFLOP/s (forward + 2x backward, algorithmic)")
     lf, gmf, grf, Yf = res["fp32"]
     lb, gmb, grb, Yb = res["bf16"]
