@@ -77,16 +77,27 @@ __device__ __forceinline__ bf16x8 row_frag(int lane, const __bf16* T, int stride
     return *reinterpret_cast<const bf16x8*>(T + (row0 + (lane & 31)) * stride + k0 + 8 * (lane >> 5));
 }
 
-// lane (r, h) <- T[k0 + 8h + j][col0 + r], j = 0..7: per 16-lane group two 4-row x 16-column blocks read column-major
-// (ds_read_b64_tr_b16: lane 4q+p of a group supplies the address of block row q, columns 4p .. 4p+3, and receives column
-// (lane & 15) of the four rows).  EXEC must be all ones: callers keep these reads out of lane-divergent code.
+// Transposed fragment of the 16 tile rows k0 .. k0+15 at columns col0 .. col0+31: lane (r, h) <- T[row(h, j)][col0 + r], j = 0..7
+// (two ds_read_b64_tr_b16: lane 4q+p of a 16-lane group supplies the address of one row's columns 4p .. 4p+3, and receives
+// column (lane & 15) of the group's four rows).  EXEC must be all ones: callers keep these reads out of lane-divergent code.
+//   SPREAD (default): row(h, j) = k0 + 4 (j & 3) + 2h + (j >> 2).  The four rows one 32-lane pass touches are then 4 apart: with
+//     row strides of 4 mod 16 dwords (all of the tiles here) they fall into four different quarters of the 64 banks and the read
+//     is conflict-free; with consecutive rows (row = k0 + 8h + j) it is 2- to 4-way conflicted, and the backward kernel's LDS
+//     array was busy 71 % of the time, 57 % of it conflict cycles (PMC).  Which of the 16 rows lands in which k slot does not
+//     matter when both operands of the MFMA come from this loader (the weight gradients: k = batch row); for the input
+//     gradients the weight images are staged with their rows in this order (stage_weights<true>).
+//   !SPREAD: row(h, j) = k0 + 8h + j, for a weight image in natural row order (the recomputing build, whose forward pass reads
+//     the same image row-wise).
+template <bool SPREAD = true>
 __device__ __forceinline__ bf16x8 tr_frag(int lane, const __bf16* T, int stride, int k0, int col0) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const __bf16* a = T + (k0 + 8 * (g >> 1) + q) * stride + col0 + 16 * (g & 1) + 4 * p;
+    const __bf16* a = T + (SPREAD ? k0 + 4 * q + 2 * (g >> 1) : k0 + 8 * (g >> 1) + q) * stride + col0 + 16 * (g & 1) + 4 * p;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * stride));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + (SPREAD ? 1 : 4) * stride));
     return __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
+// where stage_weights<true> puts row o of a weight image: k slot 8h + 4e + q of its 16-row block -> row 4q + 2h + e
+__device__ __forceinline__ int spread_row(int o) { return (o & ~15) + 4 * (o & 3) + 2 * ((o >> 3) & 1) + ((o >> 2) & 1); }
 
 // The lane id, opaque to the optimiser: addresses derived from it are computed where they are used instead of being hoisted out
 // of the tile loop, where two dozen of them would stay live beside the accumulators (128 registers per lane at 16 waves).
@@ -129,17 +140,18 @@ __device__ __forceinline__ void store_activation(const f32x16& acc, __bf16* hout
 }
 
 // the pair's layer-1 / layer-2 weights -> bf16 LDS images, biases and the output layer -> fp32 (once per workgroup)
+template <bool SPREAD>
 __device__ __forceinline__ void stage_weights(const Lds& l, const float* __restrict__ w, int F) {
     const int t = threadIdx.x;
     for (int i = t; i < H2 * H1 / 4; i += NT) {
         const int o = i / (H1 / 4), k = 4 * (i % (H1 / 4));
         const float4 v = *reinterpret_cast<const float4*>(w + flat_w_off(F, 1) + (int64_t)o * H1 + k);
-        *reinterpret_cast<bf16x4*>(l.w1 + o * SW1 + k) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(l.w1 + (SPREAD ? spread_row(o) : o) * SW1 + k) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
     }
     for (int i = t; i < H3 * H2 / 4; i += NT) {
         const int o = i / (H2 / 4), k = 4 * (i % (H2 / 4));
         const float4 v = *reinterpret_cast<const float4*>(w + flat_w_off(F, 2) + (int64_t)o * H2 + k);
-        *reinterpret_cast<bf16x4*>(l.w2 + o * SW2 + k) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        *reinterpret_cast<bf16x4*>(l.w2 + (SPREAD ? spread_row(o) : o) * SW2 + k) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
     }
     if (t < H2) l.b1[t] = w[flat_b_off(F, 1) + t];
     else if (t < H2 + H3) l.b2[t - H2] = w[flat_b_off(F, 2) + t - H2];
@@ -264,7 +276,7 @@ __global__ __launch_bounds__(NT) void train_forward_bf16_kernel(const float* __r
     float xr[XN];
     load_x(xr, xm, rows, F, begin);
     const W0Frag w0 = load_w0(w, F, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 7);
-    stage_weights(l, w, F);
+    stage_weights<false>(l, w, F);
     __syncthreads();
     const int64_t tiles = (rows + TR - 1) / TR;
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
@@ -277,12 +289,13 @@ __global__ __launch_bounds__(NT) void train_forward_bf16_kernel(const float* __r
     }
 }
 
-// dH^T[in tile mi, row tile rt] = W^T . dZ: the MFMA chain (reads only)
+// dH^T[in tile mi, row tile rt] = W^T . dZ: the MFMA chain (reads only); SPREAD = the image's rows are in spread_row order
+template <bool SPREAD>
 __device__ __forceinline__ f32x16 input_grad_mfma(const __bf16* Wimg, int sw, int OUT, const __bf16* dz, int sdz, int mi, int rt) {
     const int ln = fresh_lane();
     f32x16 acc = {0};
 #pragma unroll 2
-    for (int s = 0; s < OUT / 16; ++s) acc = mfma16(tr_frag(ln, Wimg, sw, 16 * s, 32 * mi), row_frag(ln, dz, sdz, 32 * rt, 16 * s), acc);
+    for (int s = 0; s < OUT / 16; ++s) acc = mfma16(tr_frag<SPREAD>(ln, Wimg, sw, 16 * s, 32 * mi), row_frag(ln, dz, sdz, 32 * rt, 16 * s), acc);
     return acc;
 }
 // ... times d(h_in), written over h_in in place
@@ -339,7 +352,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
     load_dy(begin);
     W0Frag w0 = {};
     if (!SAVED) w0 = load_w0(w, F, wave & 7);
-    stage_weights(l, w, F);
+    stage_weights<SAVED>(l, w, F);
     __syncthreads();
     const float sc = MODE != 0 ? dm.scale : 1.0f;
     // the block's weight gradients, in registers across its tiles:
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             for (int ks = 0; ks < TR / 16; ++ks)
                 gwx = mfma16(tr_frag(ln, l.h3, S3, 16 * ks, 32 * (wave >> 2)), tr_frag(ln, l.h2, S2, 16 * ks, 32 * (wave & 3)), gwx);
         } else {
-            ig = input_grad_mfma(l.w2, SW2, H3, l.h3, S3, (wave - 8) & 3, (wave - 8) >> 2);
+            ig = input_grad_mfma<SAVED>(l.w2, SW2, H3, l.h3, S3, (wave - 8) & 3, (wave - 8) >> 2);
         }
         __syncthreads();
         // ---- phase D: dz1 over h2
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
                 for (int j = 0; j < 2; ++j) gw1[j] = mfma16(tr_frag(ln, l.h2, S2, 16 * ks, 32 * (2 * (wave >> 3) + j)), b, gw1[j]);
             }
         }
-        ig = input_grad_mfma(l.w1, SW1, H2, l.h2, S2, wave & 7, wave >> 3);
+        ig = input_grad_mfma<SAVED>(l.w1, SW1, H2, l.h2, S2, wave & 7, wave >> 3);
         __syncthreads();
         // ---- phase F: dz0 over h1
         input_grad_store(ig, l.h1, S1, wave & 7, wave >> 3, sc);
