@@ -314,6 +314,15 @@ __device__ __forceinline__ void input_grad_store(const f32x16& acc, __bf16* hin,
 
 // SAVED: the forward kernel left the tiles in `act`; otherwise each tile's forward pass is recomputed here (two builds, so that
 // neither carries the other's registers: 128 per lane at four waves per SIMD)
+// Diagnostic build (-DMCMC_TB_STAMP, tools/check_train_bf16.py --stamps): workgroup (0, 0) records s_memtime at the phase
+// boundaries of its third tile and leaves the stamps in the first floats of its dW partial (which is then not a gradient).
+#ifdef MCMC_TB_STAMP
+#define TB_STAMP(i) \
+    if (stamp_tile) stamps[i] = __builtin_amdgcn_s_memtime()
+#else
+#define TB_STAMP(i)
+#endif
+
 template <int MODE, bool SAVED>
 __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
                                                                 const float* __restrict__ W, DropMask dm, const float* __restrict__ delta,
@@ -362,8 +371,15 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
     // per-thread partial sums: column t & 63 of dw3 and db2 over the rows this thread visits, db3 (lanes with column 0),
     // column t & 127 of db1 over a quarter of the rows (t < 512)
     float g_w3 = 0.0f, g_b2 = 0.0f, g_b3 = 0.0f, g_b1 = 0.0f;
+#ifdef MCMC_TB_STAMP
+    uint64_t stamps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
         const int64_t next_base = row_base + TR < end ? row_base + TR : -1;
+#ifdef MCMC_TB_STAMP
+        const bool stamp_tile = blockIdx.x == 0 && blockIdx.y == 0 && row_base == begin + 2 * TR;
+#endif
+        TB_STAMP(0);
         // ---- phase A: the tile's x, h1 | h2 | h3 and dy in LDS
         if (SAVED) {  // the forward kernel saved this tile's h1 | h2 | h3: no recompute, no masks
             const uint4* src = act + ((int64_t)pair * tiles + row_base / TR) * kActPieces;
@@ -389,6 +405,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             __syncthreads();
             if (next_base >= 0) load_dy(next_base);
         }
+        TB_STAMP(1);
         // ---- phase B: output layer.  dw3 += dy h3, db3 += dy; dz2 = dy w3 d(h3) over h3, db2 += dz2
         {
             const int k = t & 63;
@@ -406,6 +423,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             }
         }
         __syncthreads();
+        TB_STAMP(2);
         // ---- phase C: dW2 += dz2^T h2 (waves 0-7)  |  the MFMA chain of dz1 = W2^T dz2 (waves 8-15)
         f32x16 ig = {0};
         if (wave < 8) {
@@ -417,9 +435,11 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             ig = input_grad_mfma<SAVED>(l.w2, SW2, H3, l.h3, S3, (wave - 8) & 3, (wave - 8) >> 2);
         }
         __syncthreads();
+        TB_STAMP(3);
         // ---- phase D: dz1 over h2
         if (wave >= 8) input_grad_store(ig, l.h2, S2, (wave - 8) & 3, (wave - 8) >> 2, sc);
         __syncthreads();
+        TB_STAMP(4);
         // ---- phase E: dW1 += dz1^T h1, and the MFMA chain of dz0 = W1^T dz1 (all waves; both only read the tiles)
         {
             const int ln = fresh_lane();
@@ -432,9 +452,11 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
         }
         ig = input_grad_mfma<SAVED>(l.w1, SW1, H2, l.h2, S2, wave & 7, wave >> 3);
         __syncthreads();
+        TB_STAMP(5);
         // ---- phase F: dz0 over h1
         input_grad_store(ig, l.h1, S1, wave & 7, wave >> 3, sc);
         __syncthreads();
+        TB_STAMP(6);
         // ---- phase G: dW0 | db0 (column F of the input tile is 1) += dz0^T x (waves 8-15)  |  db1 += column sums of dz1 (waves 0-7)
         if (wave >= 8) {
             const int ln = fresh_lane();
@@ -447,7 +469,9 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             for (int rr = 0; rr < TR / 4; ++rr) a += (float)l.h2[(r0 + rr) * S2 + col];
             g_b1 += a;
         }
+        TB_STAMP(7);
         __syncthreads();
+        TB_STAMP(8);
     }
     // ---- the block's partial, flat layout: register i of lane (r, h) holds [out = 32 tile + acc_feature(i, h)][in = 32 tile + r]
 #pragma unroll
@@ -493,6 +517,11 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
         for (int v = 0; v < NW; ++v) a += red_b3[v];
         g[flat_b_off(F, 3)] = a;
     }
+#ifdef MCMC_TB_STAMP
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0)
+        for (int i = 0; i < 9; ++i) reinterpret_cast<uint64_t*>(g)[i] = stamps[i];
+#endif
 }
 
 DropMask make_mask(int mode, const uint8_t* m0, const uint8_t* m1, const uint8_t* m2, uint64_t seed, float p_drop) {

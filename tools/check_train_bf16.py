@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--mask", default="philox")
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--nb", type=int, default=0, help="bf16: pin the row blocks per pair")
+    ap.add_argument("--stamps", action="store_true", help="library built with -DMCMC_TB_STAMP: print the backward kernel's phase times")
     ap.add_argument("--no-save", action="store_true", help="bf16: recompute the forward pass in the backward kernel")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -58,6 +59,9 @@ def main():
             flop = 3 * 2 * (a.F * 256 + 256 * 128 + 128 * 64 + 64) * a.M * a.S * a.rows
             if dt == "bf16":
                 print("row blocks per pair:", tr._bf16_row_blocks(a.rows))
+                if a.stamps:
+                    st = tr.dW[0, :18].cpu().view(torch.int64).tolist()
+                    print("backward phases A..G, barrier (shader-clock cycles):", [st[i + 1] - st[i] for i in range(8)], "tile:", st[8] - st[0])
             print(f"{dt}: {ms:.3f} ms per step  {flop / ms / 1e9:.1f} TFLOP/s (forward + 2x backward, algorithmic)")
     lf, gmf, grf, Yf = res["fp32"]
     lb, gmb, grb, Yb = res["bf16"]
