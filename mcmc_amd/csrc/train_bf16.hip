@@ -259,7 +259,9 @@ __device__ __forceinline__ void block_rows(int64_t rows, int64_t& begin, int64_t
 constexpr int kActElems = TR * (S1 + S2 + S3);
 static_assert((kActElems * 2) % 16 == 0, "activation tiles are copied as 16-byte pieces");
 constexpr int kActPieces = kActElems * 2 / 16;
-constexpr int AN = (kActPieces + NT - 1) / NT;  // 16-byte pieces per thread
+// in 1-KiB pieces (one LDS-DMA wave-instruction each): h1 is the first 33, h2 | h3 the other 26
+static_assert(TR * S1 * 2 % 1024 == 0 && kActElems * 2 % 1024 == 0, "the saved tile splits into whole 1-KiB pieces at h1 | h2");
+constexpr int kKiBH1 = TR * S1 * 2 / 1024, kKiBAll = kActElems * 2 / 1024;
 
 template <int MODE>
 __global__ __launch_bounds__(NT) void train_forward_bf16_kernel(const float* __restrict__ xb, int64_t x_stride, int64_t rows, int F, int S,
@@ -294,7 +296,10 @@ template <bool SPREAD>
 __device__ __forceinline__ f32x16 input_grad_mfma(const __bf16* Wimg, int sw, int OUT, const __bf16* dz, int sdz, int mi, int rt) {
     const int ln = fresh_lane();
     f32x16 acc = {0};
-#pragma unroll 2
+#ifndef TB_IG_UNROLL
+#define TB_IG_UNROLL 2
+#endif
+#pragma unroll TB_IG_UNROLL
     for (int s = 0; s < OUT / 16; ++s) acc = mfma16(tr_frag<SPREAD>(ln, Wimg, sw, 16 * s, 32 * mi), row_frag(ln, dz, sdz, 32 * rt, 16 * s), acc);
     return acc;
 }
@@ -314,6 +319,42 @@ __device__ __forceinline__ void input_grad_store(const f32x16& acc, __bf16* hin,
 
 // SAVED: the forward kernel left the tiles in `act`; otherwise each tile's forward pass is recomputed here (two builds, so that
 // neither carries the other's registers: 128 per lane at four waves per SIMD)
+// Workgroup barrier that leaves VMEM in flight: __syncthreads() drains vmcnt while an LDS-DMA load is outstanding
+// (cdna_hip_programming.md, 'Pipelining across barriers'); LDS traffic is retired by the lgkmcnt wait.
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <bool RAW>
+__device__ __forceinline__ void tile_barrier() {
+    if (RAW) barrier_lds_only();
+    else __syncthreads();
+}
+typedef __attribute__((address_space(3))) char lds_char;
+// One LDS-DMA load (global_load_lds_dwordx4: lane i's 16 bytes land at the wave-uniform LDS byte address lds_dst + 16 i), as an
+// asm statement so that hipcc does not count it: with the builtin every LDS read that follows waits vmcnt(0) for it (the
+// compiler cannot tell that the read does not alias the destination), which would expose the load in the very next phase.
+// Completion is counted by hand: s_waitcnt vmcnt(0) in the issuing wave, then a barrier, then the reads
+// (cdna_hip_programming.md, inline-asm rules: M0 is written in the statement that uses it and restored).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// 1-KiB pieces [p0, p1) of a saved tile, global -> LDS without registers (the saved image is the LDS image byte for byte),
+// pieces dealt round-robin to the waves
+__device__ __forceinline__ void dma_pieces(const uint4* src_tile, __bf16* lds_tile, int wave, int p0, int p1) {
+    const int lane = threadIdx.x & 63;
+    const unsigned base = (unsigned)(size_t)(lds_char*)reinterpret_cast<char*>(lds_tile);
+#ifdef TB_SKIP_ACT  // timing experiment (profiles/EXPERIMENTS.md): the kernel without its saved-activation traffic
+    return;
+#endif
+    for (int p = p0 + wave; p < p1; p += NW) glds16(src_tile + p * 64 + lane, __builtin_amdgcn_readfirstlane(base + p * 1024));
+}
+
 // Diagnostic build (-DMCMC_TB_STAMP, tools/check_train_bf16.py --stamps): workgroup (0, 0) records s_memtime at the phase
 // boundaries of its third tile and leaves the stamps in the first floats of its dW partial (which is then not a gradient).
 #ifdef MCMC_TB_STAMP
@@ -345,15 +386,6 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
     const int64_t tiles = (rows + TR - 1) / TR;
     float xr[XN];
     float dyr = 0.0f;  // t < TR: dLoss/dy of this thread's row of the next tile
-    // Saved activations: a register prefetch of the next tile (16 registers per lane) does not fit beside the accumulators at four
-    // waves per SIMD, so each thread touches one 128-byte line of the next tile instead (one register, consumed at the next
-    // phase A): the tile's own loads then hit L2.
-    float touch = 0.0f;
-    auto touch_act = [&](int64_t row_base) {
-        if (!SAVED) return;
-        const char* src = reinterpret_cast<const char*>(act + ((int64_t)pair * tiles + row_base / TR) * kActPieces);
-        if (t < (kActPieces * 16 + 127) / 128) touch = *reinterpret_cast<const float*>(src + 128 * t);
-    };
     auto load_dy = [&](int64_t row_base) {
         if (t < TR) dyr = row_base + t < rows ? dm_row[row_base + t] : 0.0f;
     };
@@ -362,6 +394,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
     W0Frag w0 = {};
     if (!SAVED) w0 = load_w0(w, F, wave & 7);
     stage_weights<SAVED>(l, w, F);
+    if (SAVED) dma_pieces(act + ((int64_t)pair * tiles + begin / TR) * kActPieces, l.h1, wave, kKiBH1, kKiBAll);
     __syncthreads();
     const float sc = MODE != 0 ? dm.scale : 1.0f;
     // the block's weight gradients, in registers across its tiles:
@@ -381,24 +414,19 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
 #endif
         TB_STAMP(0);
         // ---- phase A: the tile's x, h1 | h2 | h3 and dy in LDS
-        if (SAVED) {  // the forward kernel saved this tile's h1 | h2 | h3: no recompute, no masks
-            const uint4* src = act + ((int64_t)pair * tiles + row_base / TR) * kActPieces;
-            uint4 a[AN];
-#pragma unroll
-            for (int q = 0; q < AN; ++q) a[q] = t + q * NT < kActPieces ? src[t + q * NT] : uint4{0, 0, 0, 0};
+        if (SAVED) {
+            // The forward kernel saved this tile's h1 | h2 | h3: no recompute, no masks.  The tile arrives by LDS-DMA, each half
+            // while its LDS region is dead: h2 | h3 were issued in the previous tile's phase F (here: retired by vmcnt(0), then
+            // this phase's barrier, read from phase B on), h1 is issued now (retired before phase D's barrier, read in phase E).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             store_x(l, xr);
             if (t < TR) l.y[t] = dyr;
-            uint4* dst = reinterpret_cast<uint4*>(l.h1);
-#pragma unroll
-            for (int q = 0; q < AN; ++q)
-                if (t + q * NT < kActPieces) dst[t + q * NT] = a[q];
-            asm volatile("" ::"v"(touch));
-            __syncthreads();
+            dma_pieces(act + ((int64_t)pair * tiles + row_base / TR) * kActPieces, l.h1, wave, 0, kKiBH1);
             if (next_base >= 0) {
                 load_x(xr, xm, rows, F, next_base);
                 load_dy(next_base);
-                touch_act(next_base);
             }
+            barrier_lds_only();
         } else {
             forward_tile<MODE>(l, w0, xr, xm, rows, F, row_base, next_base, dm, pair, nullptr);
             if (t < TR) l.y[t] = dyr;
@@ -422,7 +450,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
                 l.h3[rr * S3 + k] = (__bf16)dz;
             }
         }
-        __syncthreads();
+        tile_barrier<SAVED>();
         TB_STAMP(2);
         // ---- phase C: dW2 += dz2^T h2 (waves 0-7)  |  the MFMA chain of dz1 = W2^T dz2 (waves 8-15)
         f32x16 ig = {0};
@@ -434,16 +462,20 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
         } else {
             ig = input_grad_mfma<SAVED>(l.w2, SW2, H3, l.h3, S3, (wave - 8) & 3, (wave - 8) >> 2);
         }
-        __syncthreads();
+        tile_barrier<SAVED>();
         TB_STAMP(3);
         // ---- phase D: dz1 over h2
         if (wave >= 8) input_grad_store(ig, l.h2, S2, (wave - 8) & 3, (wave - 8) >> 2, sc);
-        __syncthreads();
+        if (SAVED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of h1 have landed
+        tile_barrier<SAVED>();
         TB_STAMP(4);
         // ---- phase E: dW1 += dz1^T h1, and the MFMA chain of dz0 = W1^T dz1 (all waves; both only read the tiles)
         {
             const int ln = fresh_lane();
-#pragma unroll 1
+#ifndef TB_DW1_UNROLL
+#define TB_DW1_UNROLL 1
+#endif
+#pragma unroll TB_DW1_UNROLL
             for (int ks = 0; ks < TR / 16; ++ks) {
                 const bf16x8 b = tr_frag(ln, l.h1, S1, 16 * ks, 32 * (wave & 7));
 #pragma unroll
@@ -451,26 +483,28 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             }
         }
         ig = input_grad_mfma<SAVED>(l.w1, SW1, H2, l.h2, S2, wave & 7, wave >> 3);
-        __syncthreads();
-        TB_STAMP(5);
-        // ---- phase F: dz0 over h1
-        input_grad_store(ig, l.h1, S1, wave & 7, wave >> 3, sc);
-        __syncthreads();
-        TB_STAMP(6);
-        // ---- phase G: dW0 | db0 (column F of the input tile is 1) += dz0^T x (waves 8-15)  |  db1 += column sums of dz1 (waves 0-7)
-        if (wave >= 8) {
-            const int ln = fresh_lane();
-#pragma unroll
-            for (int ks = 0; ks < TR / 16; ++ks) gwx = mfma16(tr_frag(ln, l.h1, S1, 16 * ks, 32 * (wave - 8)), tr_frag(ln, l.xs, SX, 16 * ks, 0), gwx);
-        } else {
+        if (wave < 8) {  // db1 += column sums of dz1 (here, not in phase G: h2 is dead from this phase's barrier on)
             const int col = t & (H2 - 1), r0 = (t >> 7) * (TR / 4);
             float a = 0.0f;
 #pragma unroll 8
             for (int rr = 0; rr < TR / 4; ++rr) a += (float)l.h2[(r0 + rr) * S2 + col];
             g_b1 += a;
         }
+        tile_barrier<SAVED>();
+        TB_STAMP(5);
+        // ---- phase F: dz0 over h1; the next tile's h2 | h3 start to arrive in their (dead) regions
+        if (SAVED && next_base >= 0) dma_pieces(act + ((int64_t)pair * tiles + next_base / TR) * kActPieces, l.h1, wave, kKiBH1, kKiBAll);
+        input_grad_store(ig, l.h1, S1, wave & 7, wave >> 3, sc);
+        tile_barrier<SAVED>();
+        TB_STAMP(6);
+        // ---- phase G: dW0 | db0 (column F of the input tile is 1) += dz0^T x (waves 8-15)
+        if (wave >= 8) {
+            const int ln = fresh_lane();
+#pragma unroll
+            for (int ks = 0; ks < TR / 16; ++ks) gwx = mfma16(tr_frag(ln, l.h1, S1, 16 * ks, 32 * (wave - 8)), tr_frag(ln, l.xs, SX, 16 * ks, 0), gwx);
+        }
         TB_STAMP(7);
-        __syncthreads();
+        tile_barrier<SAVED>();
         TB_STAMP(8);
     }
     // ---- the block's partial, flat layout: register i of lane (r, h) holds [out = 32 tile + acc_feature(i, h)][in = 32 tile + r]
@@ -490,6 +524,7 @@ __global__ __launch_bounds__(NT) void train_backward_bf16_kernel(const float* __
             else if (r == F) g[flat_b_off(F, 0) + o] = gwx[i];
         }
     }
+    if (SAVED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // per-thread partial sums -> LDS (the h1 tile is free: the loop ended on a barrier) -> one thread per element
     float* red = reinterpret_cast<float*>(l.h1);  // [NW][64] dw3 | [NW][64] db2 | [NW] db3 | [4][128] db1
     float* red_w3 = red;
