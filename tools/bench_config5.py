@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--samples", type=int, default=10)
     ap.add_argument("--features", type=int, default=11)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--dtype", default="fp32", choices=("fp32", "bf16"), help="GEMM operand type of the large-batch kernels (EnsembleTrainer compute_dtype)")
     args = ap.parse_args()
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -46,7 +47,7 @@ def main():
     gr = torch.Generator(device=dev).manual_seed(100 + rank)
     xb = torch.randn(M, R, F, device=dev, generator=gr)
     yb = torch.randn(M, R, device=dev, generator=gr)
-    tr = EnsembleTrainer(mu, rho, F, S)
+    tr = EnsembleTrainer(mu, rho, F, S, compute_dtype=args.dtype)
     group = None if world > 1 else False
     kw = dict(group=group, global_rows=R * world, mask_seed=7 + rank)
     tr.step(xb, yb, 1e-3, 0.9, seed=1, **kw)  # warm-up
@@ -63,9 +64,11 @@ def main():
     assert torch.isfinite(loss).all()
     if rank == 0:
         pair_rows = M * S * R * world
-        print(json.dumps({"world": world, "rows_per_rank": R, "members": M, "samples": S, "ms_per_step": dt * 1e3,
+        bf16 = args.dtype == "bf16" and int(tr.eng.lib.mcmc_train_row_blocks(R)) > 1
+        print(json.dumps({"world": world, "dtype": args.dtype, "rows_per_rank": R, "members": M, "samples": S, "ms_per_step": dt * 1e3,
                           "pair_rows_per_s": pair_rows / dt, "algorithmic_tflops": 3 * 87680 * pair_rows / dt / 1e12,
-                          "row_blocks": int(tr.eng.lib.mcmc_train_row_blocks(R)), "loss": [round(float(x), 5) for x in loss.cpu()]}))
+                          "row_blocks": tr._bf16_row_blocks(R) if bf16 else int(tr.eng.lib.mcmc_train_row_blocks(R)),
+                          "saved_activations": (getattr(tr, "_act16", None) is not None) if bf16 else bool(tr._save_act), "loss": [round(float(x), 5) for x in loss.cpu()]}))
     if world > 1:
         dist.destroy_process_group()
 

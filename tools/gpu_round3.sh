@@ -19,11 +19,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_loss -- python3 tools/bench_loss.py > $out/prof_loss.log 2>&1 || { echo LOSS PROF FAILED; tail -5 $out/prof_loss.log; exit 1; }
 # widened rows: training step (reference batch size and config-5 size), TFT step
 : > $out/train.jsonl
-for cmd in "tools/bench_train.py" "tools/bench_config5.py --rows 65536" "tools/bench_config5.py --rows 1048576" "tools/bench_train_kernels.py" "tools/bench_tft.py"; do
+for cmd in "tools/bench_train.py" "tools/bench_config5.py --rows 65536" "tools/bench_config5.py --rows 1048576" "tools/bench_config5.py --rows 65536 --dtype bf16" "tools/bench_config5.py --rows 1048576 --dtype bf16" "tools/bench_train_kernels.py" "tools/bench_tft.py"; do
   timeout -k 10 200 python3 $cmd 2> $out/train.err | tail -1 >> $out/train.jsonl || { echo "TRAIN BENCH FAILED: $cmd"; tail -5 $out/train.err; exit 1; }
 done
 cat $out/train.jsonl
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -- python3 tools/bench_config5.py --rows 65536 > $out/prof_train.log 2>&1 || { echo TRAIN PROF FAILED; tail -5 $out/prof_train.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train_bf16 -- python3 tools/bench_config5.py --rows 65536 --dtype bf16 > $out/prof_train_bf16.log 2>&1 || { echo TRAIN BF16 PROF FAILED; tail -5 $out/prof_train_bf16.log; exit 1; }
 fi
 mkdir -p $out/pmc_fwd $out/pmc_red
 pmc() {  # pmc <dir> <counters...> -- <program args...>

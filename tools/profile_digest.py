@@ -7,7 +7,7 @@
   <tag>_bench_kernel_stats.csv     rocprofv3 --kernel-trace --stats of bench.py (steps 2, warmup 1)
   <tag>_loss_kernel_stats.csv      the same for tools/bench_loss.py
   <tag>_train_kernel_stats.csv     the same for tools/bench_config5.py --rows 65536 (large-batch training step)
-  <tag>_train.jsonl                one line each: bench_train (32-row step), bench_config5 at 65,536 and 1,048,576 rows, bench_train_kernels, bench_tft
+  <tag>_train.jsonl                one line each: bench_train (32-row step), bench_config5 at 65,536 and 1,048,576 rows (fp32, then bf16), bench_train_kernels, bench_tft
   <tag>_pmc_forward.csv / .json    PMC passes over tools/bench_forward.py (--dtype bf16_fast, 3.65 M rows x 256 pairs)
   <tag>_pmc_train.csv              PMC passes over tools/bench_train_kernels.py (65,536 rows x 80 pairs: forward / backward, recomputing and saved)
   <tag>_pmc_reduce.csv / .json     PMC passes over tools/bench_reduce.py (262,144 rows x 8,192 pairs: a bench row block)
@@ -76,6 +76,8 @@ def main():
     stats_csv(os.path.join(src, "prof"), os.path.join(prof, f"{tag}_bench_kernel_stats.csv"))
     stats_csv(os.path.join(src, "prof_loss"), os.path.join(prof, f"{tag}_loss_kernel_stats.csv"))
     stats_csv(os.path.join(src, "prof_train"), os.path.join(prof, f"{tag}_train_kernel_stats.csv"))
+    if os.path.isdir(os.path.join(src, "prof_train_bf16")):
+        stats_csv(os.path.join(src, "prof_train_bf16"), os.path.join(prof, f"{tag}_train_bf16_kernel_stats.csv"))
     if os.path.exists(os.path.join(src, "train.jsonl")):
         shutil.copy(os.path.join(src, "train.jsonl"), os.path.join(prof, f"{tag}_train.jsonl"))
     fwd = pmc(os.path.join(src, "pmc_fwd"), "forward_bf16")
