@@ -102,7 +102,8 @@ class GPUBayesianEnsemble(nn.Module):
         1e-3 / wd 0.01), OneCycleLR schedule, clip_grad_norm_(1.0), per-member shuffles and early
         stopping (patience 25) - but all members advance together, one fused HIP step per batch
         (mcmc_amd.train.EnsembleTrainer) instead of the reference's member-after-member torch graph.
-        Weight noise and dropout masks come from the keyed Philox streams."""
+        Weight noise and dropout masks come from the keyed Philox streams.  With ``compute_dtype`` bf16 / bf16_fast and a
+        ``batch_size`` of 2,048 rows or more the step runs on the bf16-operand kernels (fp32 master weights and AdamW)."""
         if isinstance(X, bool) and y is None:  # nn.Module.train(mode) - the reference shadows it; keep both usable
             return super().train(X)
         from .train import EnsembleTrainer, fit_ensemble
@@ -116,7 +117,10 @@ class GPUBayesianEnsemble(nn.Module):
         self.models = []
         members = [BayesianNetwork(self.input_dim).to(self.device) for _ in range(self.n_models)]
         mu, rho = engine.pack_members(members, torch.device(self.device))
-        trainer = EnsembleTrainer(mu, rho, self.input_dim, num_samples)
+        # bf16 ensembles use the bf16-operand training kernels where those exist: batches of more than one row block
+        # (>= 2,048 rows; the reference's batch_size of 32 runs the fp32 one-call step either way)
+        trainer = EnsembleTrainer(mu, rho, self.input_dim, num_samples,
+                                  compute_dtype="bf16" if self.compute_dtype in ("bf16", "bf16_fast") else "fp32")
         self.epochs_trained = fit_ensemble(trainer, X.rename(None), y.rename(None), epochs=epochs, batch_size=self.batch_size,
                                            seed=self._next_seed())
         trainer.unpack_into(members)

@@ -181,6 +181,29 @@ def test_bf16_saved_activations_equal_recompute(rows, mask):
         assert torch.equal(a, b)
 
 
+def test_bf16_step_does_not_depend_on_row_blocks():
+    """The bf16 kernels take any number of row blocks per pair (EnsembleTrainer picks it from a makespan model): 1, 3, 7 and 64
+    blocks over 2,100 rows - 33 tiles of 64 rows, so with 64 blocks 31 of them are empty and write zero partials - give the same
+    loss (same forward tiles: bit for bit) and the same gradients up to the fp32 summation order of the partials."""
+    from mcmc_amd.train import EnsembleTrainer
+    F, M, S, rows = 11, 2, 2, 2100
+    mu, rho = _members(F, M, 21)
+    xb, yb = _batch(M, rows, F, 79)
+    out = []
+    for nb in (1, 3, 7, 64):
+        tr = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S, compute_dtype="bf16")
+        tr.bf16_row_blocks = nb
+        loss = tr.step(xb.to(DEV), yb.to(DEV), 1e-3, 0.9, seed=11, mask_seed=12).clone()
+        out.append((loss.cpu(), tr.gmu.cpu().clone(), tr.grho.cpu().clone()))
+    for loss, gmu, grho in out[1:]:
+        assert torch.equal(loss, out[0][0])
+        for got, want in ((gmu, out[0][1]), (grho, out[0][2])):
+            assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # the model's own choice is a valid count
+    nb = EnsembleTrainer(mu.to(DEV), rho.to(DEV), F, S, compute_dtype="bf16")._bf16_row_blocks(65536)
+    assert 1 <= nb <= 64
+
+
 def test_train_replays_reference_trajectory(golden):
     """Both golden members stepped together with the eps / masks / lr / beta1 the reference used."""
     from mcmc_amd.train import EnsembleTrainer
