@@ -269,6 +269,8 @@ int mcmc_train_backward_saved(mcmc_ctx* ctx, const float* xb, int64_t rows, int 
  * accumulation; master weights, mcmc_train_sample, mcmc_train_loss, mcmc_train_grad and mcmc_train_apply stay fp32.  fp32 MFMA
  * runs at 1/16 of the bf16 rate, which bounds the fp32 kernels at 10^5 .. 10^6 rows per step.  Reads only W ([out][in] per layer,
  * 16-byte aligned) and writes dW [M*S*row_blocks, P] partials like mcmc_train_backward_blocks.
+ * row_blocks: any count in [1, 65535], the same in both calls (these kernels cut a pair's rows into row_blocks runs of whole 64-row
+ * tiles themselves; blocks beyond the last tile write zero partials) - mcmc_train_row_blocks(rows) is not required here.
  * act: optional device buffer of n_members*n_samples*mcmc_train_act_bytes_bf16(rows) bytes (16-byte aligned; 0.9 KB per pair
  * and row): the forward kernel leaves every tile's activations there and the backward kernel reloads them - autograd's saved
  * tensors, :178; dropped elements are stored as -0.0, so the masks are not drawn again.  NULL in both calls: the backward kernel

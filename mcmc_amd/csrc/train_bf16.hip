@@ -22,8 +22,12 @@
 // The weight gradients of a row block stay in accumulator registers across its tiles (48 per lane: wave w owns two 32 x 32
 // tiles of dW1 and one of dW2 (w < 8) or dW0 (w >= 8)) and are written once, as the block's partial
 // dW[pair * row_blocks + block] in the flat layout, for mcmc_train_grad to sum; bias and output-layer gradients are per-thread
-// partial sums reduced across the workgroup at the end of the block.  ELU, dropout masks (host or the 'MASK' Philox stream,
+// partial sums reduced across the workgroup at the end of the block.  Dropout masks (host or the 'MASK' Philox stream,
 // dropmask.hpp) and the -0.0 marking of dropped elements are those of the fp32 kernels.
+// The forward kernel can leave h1 | h2 | h3 of every tile in global memory (the LDS image byte for byte); the backward kernel
+// then reloads them by LDS-DMA, each part while its LDS region is dead (phases: see the kernel), instead of recomputing the
+// tile's forward pass (second build of the kernel; identical results).
+// History, phase timings and what bounds the kernels now: profiles/EXPERIMENTS.md section 4b.
 #include "common.hpp"
 #include "dropmask.hpp"
 
