@@ -47,11 +47,12 @@ class EnsembleTrainer:
     Pair index = member * num_samples + sample keys the Philox noise / mask streams."""
 
     # The forward kernel's activations are kept for the backward kernel (autograd's saved tensors) while they fit this many
-    # bytes: 1.8 KB per pair and row - 2.9 MB at the reference's 50 pairs x 32 rows, 9.5 GB at 80 pairs x 65,536 rows.
-    # Larger batches recompute the forward tile in the backward kernel (the same numbers, ~1.2x the step time).
+    # bytes: 1.8 KB per pair and row (fp32 kernels; 0.92 KB for the bf16 kernels) - 2.9 MB at the reference's 50 pairs x 32 rows,
+    # 9.5 GB at 80 pairs x 65,536 rows, 79 GB (bf16) at 80 pairs x 1,048,576 rows: sized for the 288 GB of an MI355X.
+    # Larger batches recompute the forward tile in the backward kernel (the same numbers, ~1.2-1.3x the step time).
     # The bound is the smaller of this constant (constructor argument ``act_max_bytes``) and ACT_FREE_FRACTION of the HBM that
     # is free when the buffer has to grow; an allocation that fails anyway falls back to the recompute path.
-    ACT_MAX_BYTES = 16 << 30
+    ACT_MAX_BYTES = 128 << 30
     ACT_FREE_FRACTION = 0.5
     # bf16 kernels: cost model of _bf16_row_blocks in rows (a block's fixed cost; one more partial in the gradient sum)
     BF16_BLOCK_COST_ROWS = 256

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--S", type=int, default=2)
     ap.add_argument("--mask", default="philox")
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--act-gib", type=float, default=0.0, help="bound of the saved-activation buffer in GiB (default: the trainer's)")
     ap.add_argument("--nb", type=int, default=0, help="bf16: pin the row blocks per pair")
     ap.add_argument("--stamps", action="store_true", help="library built with -DMCMC_TB_STAMP: print the backward kernel's phase times")
     ap.add_argument("--no-save", action="store_true", help="bf16: recompute the forward pass in the backward kernel")
@@ -37,7 +38,7 @@ def main():
     yb = (torch.randn(a.M, a.rows, generator=g) + (torch.rand(a.M, a.rows, generator=g) > 0.85).float() * 2.0).to(dev)
     res = {}
     for dt in ("fp32", "bf16"):
-        tr = EnsembleTrainer(mu.to(dev), rho.to(dev), a.F, a.S, compute_dtype=dt, act_max_bytes=0 if (a.no_save and dt == "bf16") else None)
+        tr = EnsembleTrainer(mu.to(dev), rho.to(dev), a.F, a.S, compute_dtype=dt, act_max_bytes=0 if (a.no_save and dt == "bf16") else (int(a.act_gib * 2 ** 30) if a.act_gib else None))
         tr.bf16_row_blocks = a.nb
         kw = dict(seed=7, dropout=(a.mask == "philox"))
         if a.mask == "host":
