@@ -133,12 +133,16 @@ __device__ __forceinline__ void store_activation(const f32x16& acc, __bf16* hout
         o[i] = acc[i] > 0.0f ? acc[i] : e;
     }
     drop16<MODE>(o, dm, layer, mo, h, pair, (uint32_t)pair, rows, row);
-    const bool live = row < rows;
+    if (row_base + TR > rows) {  // the batch's last, ragged tile (workgroup-uniform): rows past the end read as dropped
+        const bool live = row < rows;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = live ? o[i] : -0.0f;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // registers 4q .. 4q+3 hold features 8q + 4h + 0..3 (layout.hpp: acc_feature)
         bf16x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (__bf16)(live ? o[4 * q + j] : -0.0f);
+        for (int j = 0; j < 4; ++j) v[j] = (__bf16)o[4 * q + j];
         *reinterpret_cast<bf16x4*>(hout + (32 * rt + r) * stride + 32 * mo + 8 * q + 4 * h) = v;
     }
 }
@@ -180,6 +184,18 @@ __device__ __forceinline__ W0Frag load_w0(const float* __restrict__ w, int F, in
     return f;
 }
 
+// Workgroup barrier that leaves VMEM in flight: __syncthreads() drains vmcnt while an LDS-DMA load is outstanding
+// (cdna_hip_programming.md, 'Pipelining across barriers'); LDS traffic is retired by the lgkmcnt wait.
+__device__ __forceinline__ void barrier_lds_only() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+template <bool RAW>
+__device__ __forceinline__ void tile_barrier() {
+    if (RAW) barrier_lds_only();
+    else __syncthreads();
+}
 constexpr int XN = TR * KX / NT;  // input-tile elements per thread
 
 // this thread's elements of the input tile that starts at row_base (column F carries the 1.0 of the layer-0 bias)
@@ -207,10 +223,19 @@ __device__ __forceinline__ void store_x(const Lds& l, const float (&xr)[XN]) {
 // of xs / h1 (the next call's own first barrier does that for a loop of calls).
 template <int MODE>
 __device__ __forceinline__ void forward_tile(const Lds& l, const W0Frag& w0, float (&xr)[XN], const float* __restrict__ xm, int64_t rows, int F,
-                                             int64_t row_base, int64_t next_base, const DropMask& dm, int pair, float* __restrict__ Ypair) {
+                                             int64_t row_base, int64_t next_base, const DropMask& dm, int pair, float* __restrict__ Ypair,
+                                             uint64_t* stamps = nullptr) {
+#ifdef MCMC_TB_STAMP  // diagnostic build: s_memtime at the phase boundaries of the tile the caller picked
+#define FT_STAMP(i) \
+    if (stamps) stamps[i] = __builtin_amdgcn_s_memtime()
+#else
+#define FT_STAMP(i)
+#endif
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), h = lane >> 5;
+    FT_STAMP(0);
     store_x(l, xr);
-    __syncthreads();
+    barrier_lds_only();
+    FT_STAMP(1);
     if (next_base >= 0) load_x(xr, xm, rows, F, next_base);
     {  // layer 0: 8 feature tiles x 2 row tiles, one unit per wave; the bias rides on input column F
         const int mo = wave & 7, rt = wave >> 3, ln = fresh_lane();
@@ -219,7 +244,8 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const W0Frag& w0, flo
         if (F + 1 > 16) acc = mfma16(w0.a[1], row_frag(ln, l.xs, SX, 32 * rt, 16), acc);
         store_activation<MODE>(acc, l.h1, S1, mo, rt, dm, 0, pair, rows, row_base);
     }
-    __syncthreads();
+    barrier_lds_only();
+    FT_STAMP(2);
     if (wave < 2 * (H2 / 32)) {  // layer 1: 4 x 2 units
         const int mo = wave & 3, rt = wave >> 2, ln = fresh_lane();
         f32x16 acc;
@@ -229,7 +255,8 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const W0Frag& w0, flo
         for (int s = 0; s < H1 / 16; ++s) acc = mfma16(row_frag(ln, l.w1, SW1, 32 * mo, 16 * s), row_frag(ln, l.h1, S1, 32 * rt, 16 * s), acc);
         store_activation<MODE>(acc, l.h2, S2, mo, rt, dm, 1, pair, rows, row_base);
     }
-    __syncthreads();
+    barrier_lds_only();
+    FT_STAMP(3);
     if (wave < 2 * (H3 / 32)) {  // layer 2: 2 x 2 units
         const int mo = wave & 1, rt = wave >> 1, ln = fresh_lane();
         f32x16 acc;
@@ -239,7 +266,8 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const W0Frag& w0, flo
         for (int s = 0; s < H2 / 16; ++s) acc = mfma16(row_frag(ln, l.w2, SW2, 32 * mo, 16 * s), row_frag(ln, l.h2, S2, 32 * rt, 16 * s), acc);
         store_activation<MODE>(acc, l.h3, S3, mo, rt, dm, 2, pair, rows, row_base);
     }
-    __syncthreads();
+    barrier_lds_only();
+    FT_STAMP(4);
     if (Ypair && t < 8 * TR) {  // layer 3: 64 -> 1, eight threads per row
         const int rr = t >> 3, part = t & 7;
         float a = 0.0f;
@@ -250,6 +278,7 @@ __device__ __forceinline__ void forward_tile(const Lds& l, const W0Frag& w0, flo
         a += __shfl_xor(a, 4);
         if (part == 0 && row_base + rr < rows) Ypair[row_base + rr] = a + l.b3[0];
     }
+    FT_STAMP(5);
 }
 
 __device__ __forceinline__ void block_rows(int64_t rows, int64_t& begin, int64_t& end) {
@@ -285,14 +314,30 @@ __global__ __launch_bounds__(NT) void train_forward_bf16_kernel(const float* __r
     stage_weights<false>(l, w, F);
     __syncthreads();
     const int64_t tiles = (rows + TR - 1) / TR;
+#ifdef MCMC_TB_STAMP
+    uint64_t stamps[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int64_t row_base = begin; row_base < end; row_base += TR) {
-        forward_tile<MODE>(l, w0, xr, xm, rows, F, row_base, row_base + TR < end ? row_base + TR : -1, dm, pair, Y + (int64_t)pair * rows);
+#ifdef MCMC_TB_STAMP
+        uint64_t* st = blockIdx.x == 0 && blockIdx.y == 0 && row_base == begin + 2 * TR ? stamps : nullptr;
+#else
+        uint64_t* st = nullptr;
+#endif
+        forward_tile<MODE>(l, w0, xr, xm, rows, F, row_base, row_base + TR < end ? row_base + TR : -1, dm, pair, Y + (int64_t)pair * rows, st);
         if (act) {  // the tiles are complete; the next tile's first barrier comes before anything overwrites them
             uint4* dst = act + ((int64_t)pair * tiles + row_base / TR) * kActPieces;
             const uint4* src = reinterpret_cast<const uint4*>(l.h1);
             for (int i = threadIdx.x; i < kActPieces; i += NT) dst[i] = src[i];
         }
+#ifdef MCMC_TB_STAMP
+        if (st) st[6] = __builtin_amdgcn_s_memtime();
+#endif
     }
+#ifdef MCMC_TB_STAMP  // the stamps replace the first outputs of pair 0 (diagnostic build only)
+    __syncthreads();
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 7; ++i) reinterpret_cast<uint64_t*>(Y)[i] = stamps[i];
+#endif
 }
 
 // dH^T[in tile mi, row tile rt] = W^T . dZ: the MFMA chain (reads only); SPREAD = the image's rows are in spread_row order
@@ -323,18 +368,6 @@ __device__ __forceinline__ void input_grad_store(const f32x16& acc, __bf16* hin,
 
 // SAVED: the forward kernel left the tiles in `act`; otherwise each tile's forward pass is recomputed here (two builds, so that
 // neither carries the other's registers: 128 per lane at four waves per SIMD)
-// Workgroup barrier that leaves VMEM in flight: __syncthreads() drains vmcnt while an LDS-DMA load is outstanding
-// (cdna_hip_programming.md, 'Pipelining across barriers'); LDS traffic is retired by the lgkmcnt wait.
-__device__ __forceinline__ void barrier_lds_only() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-template <bool RAW>
-__device__ __forceinline__ void tile_barrier() {
-    if (RAW) barrier_lds_only();
-    else __syncthreads();
-}
 typedef __attribute__((address_space(3))) char lds_char;
 // One LDS-DMA load (global_load_lds_dwordx4: lane i's 16 bytes land at the wave-uniform LDS byte address lds_dst + 16 i), as an
 // asm statement so that hipcc does not count it: with the builtin every LDS read that follows waits vmcnt(0) for it (the

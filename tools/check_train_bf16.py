@@ -62,6 +62,8 @@ def main():
                 print("row blocks per pair:", tr._bf16_row_blocks(a.rows))
                 if a.stamps:
                     st = tr.dW[0, :18].cpu().view(torch.int64).tolist()
+                    sf = tr._Y.flatten()[:14].cpu().view(torch.int64).tolist()
+                    print("forward phases x-store, L0, L1, L2, L3, act copy (shader-clock cycles):", [sf[i + 1] - sf[i] for i in range(6)], "tile:", sf[6] - sf[0])
                     print("backward phases A..G, barrier (shader-clock cycles):", [st[i + 1] - st[i] for i in range(8)], "tile:", st[8] - st[0])
             print(f"{dt}: {ms:.3f} ms per step  {flop / ms / 1e9:.1f} TFLOP/s (forward + 2x backward, algorithmic)")
     lf, gmf, grf, Yf = res["fp32"]
